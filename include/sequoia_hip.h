@@ -1,0 +1,180 @@
+/*
+ * sequoia_hip.h — C ABI of libsequoia_hip.so, the MI355X (gfx950) native hot path of
+ * Sequoia tree speculative decoding.
+ *
+ * The reference (Infini-AI-Lab/Sequoia) has no FFI layer: its hot path is stock PyTorch ops
+ * called from Python.  Each entry point below replaces one op sequence of the reference; the
+ * comment on every function cites the reference lines it stands in for (paths relative to the
+ * reference checkout).  The reference-side binding is a ctypes stub.
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes, no torch / C++ types.
+ *   - fp16 tensors are passed as `const void*` / `void*` to IEEE binary16 data.
+ *   - token ids are int64 (the reference keeps `tokens` as torch.long); index arrays int32.
+ *   - every device entry point is stream-ordered, allocation-free and sync-free
+ *     (`stream` is a hipStream_t passed as void*; NULL = default stream), so that all of
+ *     them can be captured into a hipGraph.
+ *   - return value: SQ_OK (0) or a negative SQ_E* code; nothing throws.
+ *   - KV cache layout is the reference's: [L][1][H_kv][M][D] fp16 (Engine/Llama_KV.py:16-34);
+ *     a "layer" pointer addresses one [H_kv][M][D] slab.
+ */
+#ifndef SEQUOIA_HIP_H
+#define SEQUOIA_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQ_OK            0
+#define SQ_EINVAL       -1   /* bad argument (null pointer, negative size, ...)              */
+#define SQ_EUNSUPPORTED -2   /* shape outside what the kernels are built for               */
+#define SQ_ELAUNCH      -3   /* HIP reported an error at launch; see sq_last_error()        */
+
+#define SQ_MAX_TREE      512 /* max tree nodes (ancestor bitmask = 8 x u64 words)           */
+#define SQ_MASK_WORDS(n) (((n) + 63) / 64)
+#define SQ_MAX_TOPK      128 /* max children per parent / samples per row                   */
+#define SQ_RESULT_INTS   64  /* size of the int32 step-result record, see below             */
+
+/* Step-result record written by sq_verify_* (device memory, int32[SQ_RESULT_INTS]).        */
+#define SQ_RES_ACCEPT_LEN 0  /* a = len(accept_list) = gt + #accepted tree nodes            */
+#define SQ_RES_N_TREE     1  /* #accepted tree nodes                                        */
+#define SQ_RES_BONUS      2  /* bonus token id written to tokens[a], -1 when terminal       */
+#define SQ_RES_TERMINAL   3  /* 0 / 1                                                       */
+#define SQ_RES_REASON     4  /* 0 none, 1 EOS token accepted, 2 NaN residual                */
+#define SQ_RES_GT         5  /* echo of the ground_truth_len the step ran with              */
+#define SQ_RES_LAST_NODE  6  /* tree-local id of the node the walk stopped at               */
+#define SQ_RES_SLOTS      8  /* [8, 8+N_TREE): absolute slots of the accepted tree nodes    */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int         sq_version(void);                 /* 10000*major + 100*minor + patch            */
+const char* sq_last_error(void);              /* last HIP error string seen by this thread  */
+int         sq_device_ready(void);            /* 1 if a gfx950 device is visible, else 0    */
+
+/* ---- a1: tree-causal mask from the growmap ----------------------------------------------
+ * Host helper.  Builds the ancestor-or-self bitmask of every tree node from the children
+ * CSR (`Successors`, tree_search.py:121-128).  bit j of row i is set iff j is an ancestor of i
+ * or j == i  ==  growmap["mask"][i][j] (Tree/SpecTree.py:45-48).
+ * out: uint64[n][words], words >= SQ_MASK_WORDS(n).                                         */
+int sq_tree_bitmask_from_successors(const int32_t* child_off, const int32_t* child_ids,
+                                    int n, uint64_t* out, int words);
+
+/* Device.  Materialises rows of the reference's dense additive mask
+ * (Tree/Tree.py:20-27, Tree/SpecTree.py:54-58): out[i][c] = 0 where query slot q_slot0+i may
+ * attend key slot c, else -65504.  Rule: rows < gt are causal (c <= slot); a tree row
+ * (slot >= gt, tree id t = slot-(gt-1)) sees every c < gt plus c = gt-1+j for ancestors-or-self
+ * j of t; nothing at c >= gt+n-1.  out: fp16 [q_len][out_stride].                            */
+int sq_tree_mask_dense_f16(void* out, int out_stride, int n_cols,
+                           int q_slot0, int q_len, int gt, int n_tree,
+                           const uint64_t* d_bitmask, int words, void* stream);
+
+/* ---- a5: KV slot scatter / accepted-path compaction ------------------------------------- */
+/* KV_Cache.update_kv_cache for one layer (Engine/Llama_KV.py:72-89):
+ * cache[h][storage_ids[i]][:] = new[h][i][:].  new_k/new_v: fp16 [H_kv][q_len][D].          */
+int sq_kv_scatter_f16(void* k_layer, void* v_layer, const void* new_k, const void* new_v,
+                      const int64_t* d_storage_ids, int q_len, int h_kv, int m, int d,
+                      void* stream);
+
+/* KV_Cache.gather_kv_incremental over all layers (Engine/Llama_KV.py:60-68):
+ * for j < count: cache[..., dst_offset+j, :] = cache[..., slots[j], :] (all reads of a
+ * (layer, head) tile happen before its writes, so overlapping src/dst is safe);
+ * then rows [dst_offset+count, zero_end) are zeroed (zero_end <= m; pass zero_end = m for the
+ * reference's full-tail clear, gt+n-1 for dirty-range only, 0 for none).
+ * count = *d_count if d_count != NULL else max_count.  slots are ascending absolute slots.   */
+int sq_kv_compact_f16(void* k_cache, void* v_cache, int n_layers, int h_kv, int m, int d,
+                      const int32_t* d_slots, const int32_t* d_count, int max_count,
+                      int dst_offset, int zero_end, void* stream);
+
+/* KV_Cache.clear (Engine/Llama_KV.py:91-94) restricted to rows [0, used_rows) of every
+ * (layer, head): rows never written are already zero.                                       */
+int sq_kv_clear_f16(void* k_cache, void* v_cache, int n_layers, int h_kv, int m, int d,
+                    int used_rows, void* stream);
+
+/* ---- a3/a4: RoPE + KV write + tree-batched attention ------------------------------------ */
+/* Fused replacement of apply_rotary_pos_emb (Engine/offload_engine.py:42-67 semantics, called
+ * at Engine/Llama_modules.py:118,214) + update_kv_cache (:120,217).
+ * qkv: fp16 [q_len][(H + 2*H_kv)*D] (row stride qkv_stride elements), packed q | k | v.
+ * q_out: fp16 [H][q_len][D]; rotated K and V rows are written to cache slot storage_ids[i].
+ * cos/sin: fp16 [max_pos][D] tables exactly as LlamaRotaryEmbedding_FI builds them
+ * (Engine/Llama_modules.py:31-45); arithmetic rounds to fp16 after every op like the
+ * reference's fp16 tensor expression q*cos + rotate_half(q)*sin.                             */
+int sq_rope_kv_write_f16(const void* qkv, int qkv_stride, void* q_out,
+                         void* k_layer, void* v_layer,
+                         const void* cos_tab, const void* sin_tab,
+                         const int64_t* d_position_ids, const int64_t* d_storage_ids,
+                         int q_len, int n_heads, int h_kv, int d, int m, void* stream);
+
+/* Tree-batched attention for one layer (LlamaAttention_FI.forward Engine/Llama_modules.py:
+ * 124-134 and LlamaAttention_TG.forward :220-248): out = softmax(q k^T * scale + mask) v over
+ * key slots [0, kv_len), fp32 softmax, MFMA for q k^T and p v.
+ * q: fp16 [H][q_len][D]; out: fp16 [q_len][H*D] (the layout o_proj consumes).
+ * mask_mode 0: dense additive fp16 mask [q_len][mask_stride] (the reference's attn_mask);
+ * mask_mode 1: implicit tree mask = same rule as sq_tree_mask_dense_f16, query i sits at slot
+ *              q_slot0 + i.                                                                 */
+int sq_tree_attention_f16(const void* q, const void* k_layer, const void* v_layer, void* out,
+                          int q_len, int n_heads, int h_kv, int d, int m, int kv_len,
+                          float scale, int mask_mode,
+                          const void* dense_mask, int mask_stride,
+                          int q_slot0, int gt, int n_tree,
+                          const uint64_t* d_bitmask, int words, void* stream);
+
+/* ---- a2: draft expansion samplers ------------------------------------------------------- */
+/* utils.sampling_without_replacement (utils.py:10-18) for n_rows rows:
+ * q = softmax(logits/T) (fp16), key = log(u)/q (fp16), take the k largest keys per row in
+ * descending order (ties: lower token id first).
+ * logits: fp16 rows of length V, row r at logits + row_ids[r]*ld_logits (row_ids NULL = r);
+ * rand likewise with ld_rand.  Output, int64:
+ *   d_branch == NULL : out[r*k + s] = s-th sample of row r               (callable contract)
+ *   d_branch != NULL : out[d_out_off[r] + s] for s < d_branch[r]          (fused gather,
+ *                      = tokens[num_nodes:...] = new[sample_gather_indices], SpecTree.py:104) */
+int sq_sample_wor_f16(const void* logits, int64_t ld_logits, const void* rand, int64_t ld_rand,
+                      const int32_t* d_row_ids, int n_rows, int vocab, int k, float temperature,
+                      int64_t* out, const int32_t* d_branch, const int32_t* d_out_off,
+                      void* stream);
+
+/* utils.sampling_argmax (utils.py:29-32): top-k token ids of the raw logits, descending,
+ * ties: lower token id first.  Same addressing / output modes as sq_sample_wor_f16.          */
+int sq_topk_f16(const void* logits, int64_t ld_logits, const int32_t* d_row_ids, int n_rows,
+                int vocab, int k, int64_t* out, const int32_t* d_branch,
+                const int32_t* d_out_off, void* stream);
+
+/* ---- a6/a7/a8: verification ------------------------------------------------------------- */
+size_t sq_verify_workspace_bytes(int n_tree);
+
+/* SpecTree.verify after the target forward (Tree/SpecTree.py:196-227) with accept_step
+ * (:136-157) and get_residual (utils.py:5-8), top_p = 1:
+ *   p_t = softmax(target_logits[t]/T) for every node t; walk from the root: for the children c
+ *   of the current node in order, accept c iff p[tok_c] > r[slot_c]*q[tok_c] (fp16, strict);
+ *   on reject p <- relu(p-q)/sum(relu(p-q)), draft_logits[node][tok_c] <- -65504,
+ *   q <- softmax(draft_logits[node]/T).  Stop at the first node with no accepted child; an
+ *   accepted token in {0,2} makes the step terminal (reason 1); a NaN residual makes it
+ *   terminal (reason 2); otherwise the bonus token is drawn from the residual by exact
+ *   inverse-CDF with the caller's 24-bit uniform `bonus_u24` (replaces multinomial(1), :222).
+ * Side effects (all in device memory, no host sync):
+ *   tokens[gt .. a) = tokens[accepted slots], tokens[a] = bonus           (:224, :222)
+ *   draft_logits rows of the walked nodes get the -65504 writes           (:156)
+ *   result record filled (see SQ_RES_*).
+ * target_logits: fp16 [n_tree][V]; draft_logits: fp16 [>= n_tree][V] (tree-local rows);
+ * tokens: int64 [M]; r: fp16 [M]; children CSR over tree-local ids.                          */
+int sq_verify_stochastic_f16(const void* target_logits, void* draft_logits,
+                             int64_t* tokens, const void* r,
+                             const int32_t* d_child_off, const int32_t* d_child_ids,
+                             int n_tree, int vocab, int gt, float temperature,
+                             uint32_t bonus_u24, void* workspace, int32_t* d_result,
+                             void* stream);
+
+/* GreedyTree.verify after the target forward (Tree/GreedyTree.py:186-207): argmax per node,
+ * walk by token equality, bonus = target argmax at the last accepted node.  tokens are only
+ * compacted / bonus written when not terminal... the compaction tokens[:a] happens always
+ * (:204), the bonus write only when not terminal (:206-207).                                */
+int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens,
+                         const int32_t* d_child_off, const int32_t* d_child_ids,
+                         int n_tree, int vocab, int gt, void* workspace, int32_t* d_result,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQUOIA_HIP_H */

@@ -1,0 +1,292 @@
+"""Generate golden traces by running the REFERENCE ITSELF (imported from /root/reference).
+
+Runs only in the build container (the reference checkout does not exist on the GPU box);
+its outputs are the committed fixtures tests/golden/*.npz.  Usage:
+
+    python oracle/gen_golden.py            # writes tests/golden/
+
+The reference is imported unmodified, with the shims SURVEY.md §8(c) lists, applied from the
+outside:
+  1. Engine.Llama_modules.apply_rotary_pos_emb <- the reference's own 4.36-semantics copy in
+     Engine/offload_engine.py:42-67 (transformers 5.x dropped the position_ids argument);
+  2. a LlamaConfig subclass exposing `rope_theta`; 3. config.rope_scaling = None;
+  4. engines are built without from_pretrained (no weights offline): seeded random init;
+  5. the CUDA-graph factories are replaced by the plain functions they wrap
+     (utils.sampling_without_replacement / sampling_argmax / get_residual);
+  6. `residual.multinomial(1)` (Tree/SpecTree.py:222) draws from the device RNG stream, which
+     is not portable; it is replaced by the exact inverse-CDF rule of oracle/ops_np.py fed
+     with a recorded 24-bit uniform per step.  This changes the sampling primitive, not the
+     algorithm (same distribution), and is what the native path implements.
+
+Recorded per case: model weights (tiny models), prompt, noise (r, rand), and per speculation
+step the inputs/outputs of every hot-path op (draft logits rows + noise -> sampled children;
+target logits, draft logits, tokens, r -> accept list, residual, bonus; KV checksums).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("SEQUOIA_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+
+from oracle import ops_np  # noqa: E402
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import Engine.Llama_modules as LM
+    import Engine.offload_engine as OE
+    LM.apply_rotary_pos_emb = OE.apply_rotary_pos_emb  # shim 1
+    import Engine.Llama_model as MM
+    from Engine.Engine import (GraphInferenceEngine, GraphInferenceEngineTG, InferenceEngine,
+                               InferenceEngineTG)
+    from Engine.Llama_KV import KV_Cache
+    from Tree.SpecTree import SpecTree
+    from Tree.GreedyTree import GreedyTree
+    import utils as RU
+    from transformers import LlamaConfig
+
+    class Cfg436(LlamaConfig):  # shim 2
+        @property
+        def rope_theta(self):
+            return 10000.0
+
+    return dict(LM=LM, MM=MM, GIE=GraphInferenceEngine, GIETG=GraphInferenceEngineTG, IE=InferenceEngine,
+                IETG=InferenceEngineTG, KV=KV_Cache, SpecTree=SpecTree, GreedyTree=GreedyTree, RU=RU,
+                Cfg=Cfg436)
+
+
+def make_cfg(R, dims, vocab):
+    hidden, inter, layers, heads, kv_heads = dims
+    cfg = R["Cfg"](vocab_size=vocab, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                   num_attention_heads=heads, num_key_value_heads=kv_heads, max_position_embeddings=2048)
+    cfg.rope_scaling = None  # shim 3
+    return cfg
+
+
+def make_engine(R, outer, inner, model_cls, cfg, M, seed, logit_gain, dt=torch.float16):
+    torch.manual_seed(seed)  # shim 4
+    e = outer.__new__(outer)
+    e.device = "cpu"; e.dtype = dt; e.max_length = M; e.callables = {}; e.mempool = None
+    n = inner.__new__(inner)
+    n.device = "cpu"; n.dtype = dt; n.max_length = M
+    model = model_cls(cfg)
+    with torch.no_grad():
+        model.lm_head.weight.mul_(logit_gain)
+    n.model = model.to(dt).eval(); n.model_config = cfg
+    n.kv_cache = R["KV"](config=cfg, max_length=M, device="cpu", dtype=dt)
+    e.engine = n
+    return e
+
+
+def state_arrays(model, prefix):
+    out = {}
+    for k, v in model.state_dict().items():
+        out[f"{prefix}/{k}"] = v.detach().cpu().numpy()
+    return out
+
+
+def kv_checksum(engine):
+    kc = engine.engine.kv_cache
+    return np.array([float(kc.k_cache.float().abs().sum()), float(kc.v_cache.float().abs().sum()),
+                     float(kc.kv_offset)], dtype=np.float64)
+
+
+def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, prompt_len, max_steps, seed,
+             logit_gain=24.0, share_weights=0.0, out_dir=None):
+    """mode: 'stochastic' (SpecTree) or 'greedy' (GreedyTree)."""
+    RU = R["RU"]
+    g = torch.load(growmap_path, weights_only=False)
+    n = g["size"]
+    cfg_d = make_cfg(R, draft_dims, vocab)
+    cfg_t = make_cfg(R, target_dims, vocab)
+    draft = make_engine(R, R["GIE"], R["IE"], R["MM"].LlamaForCausalLM_FI, cfg_d, M, 1, logit_gain)
+    target = make_engine(R, R["GIETG"], R["IETG"], R["MM"].LlamaForCausalLM_TG, cfg_t, M, 2, logit_gain)
+    if share_weights > 0.0:
+        # correlated draft: draft weights = target weights + noise (same dims required)
+        assert draft_dims == target_dims
+        torch.manual_seed(3)
+        sd_t = target.engine.model.state_dict()
+        sd_d = draft.engine.model.state_dict()
+        for k in sd_d:
+            noise = torch.randn_like(sd_t[k].float()) * sd_t[k].float().std() * share_weights
+            sd_d[k].copy_((sd_t[k].float() + noise).half())
+    arrays = {}
+    arrays.update(state_arrays(draft.engine.model, "draft"))
+    arrays.update(state_arrays(target.engine.model, "target"))
+
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    prefix = torch.randint(3, vocab, (prompt_len,))
+    u24 = np.random.RandomState(seed + 1).randint(0, 1 << 24, size=max_steps + 4).astype(np.int64)
+    arrays["prompt"] = prefix.numpy()
+    arrays["bonus_u24"] = u24
+
+    n_levels = len(g["roots"]) - 1
+    if mode == "stochastic":
+        samp = {i: (lambda k: lambda lg, rnd: RU.sampling_without_replacement(lg, rnd, k, T))(max(g["branches"][i]))
+                for i in range(n_levels)}  # shim 5
+    else:
+        samp = {i: (lambda k: lambda lg: RU.sampling_argmax(lg, k))(max(g["branches"][i])) for i in range(n_levels)}
+    gidx = {i: torch.cat([torch.arange(b) + j * max(g["branches"][i]) for j, b in enumerate(g["branches"][i])])
+            for i in range(n_levels)}
+
+    # record sampler I/O by wrapping the callables
+    samp_log = []
+
+    def wrap(i, fn):
+        def run(*a):
+            out = fn(*a)
+            samp_log.append((i, [x.clone().numpy() for x in a], out.clone().numpy()))
+            return out
+        return run
+    samp = {i: wrap(i, fn) for i, fn in samp.items()}
+
+    # shim 6: deterministic bonus draw
+    step_box = {"i": 0, "last_residual": None}
+    orig_multinomial = torch.Tensor.multinomial
+
+    def fake_multinomial(self, num_samples=1, replacement=False, generator=None):
+        p = self.detach().clone().numpy()
+        step_box["last_residual"] = p
+        tok = ops_np.inverse_cdf(p, int(u24[step_box["i"]]))
+        return torch.tensor([tok], dtype=torch.long)
+
+    torch.Tensor.multinomial = fake_multinomial
+    try:
+        cls = R["SpecTree"] if mode == "stochastic" else R["GreedyTree"]
+        torch.manual_seed(seed + 7)  # noise seed: r then rand are drawn inside the ctor
+        tree = cls(prefix=prefix, device="cpu", temperature=T, top_p=1.0, draft_kv_len=0, target_kv_len=0,
+                   draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
+                   grow_map=g, attn_mask=torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16),
+                   sequence=None, new_tokens_buffer=None, parents_buffer=None,
+                   position_ids=torch.zeros(M).long(),
+                   residual_graph=RU.get_residual, sampling_callables=samp, sample_gather_indices=gidx,
+                   vocab_size=vocab)
+        if mode == "stochastic":
+            arrays["r"] = tree.r.numpy().copy()
+            arrays["rand"] = tree.rand.numpy().copy()
+        arrays["draft_logits0_prefill"] = tree.draft_logits[0].numpy().copy()
+        # mask semantics probe for the first window
+        arrays["mask_window0"] = tree.attn_mask[:prefix.shape[0] + n - 1, :prefix.shape[0] + n - 1].numpy().copy()
+
+        terminal = False
+        step = 0
+        cur_len = prompt_len
+        while step < max_steps and not terminal and cur_len + n < M:
+            gt = tree.ground_truth_len
+            samp_log.clear()
+            tree.construct_grow_map()
+            pre = f"step{step}"
+            arrays[f"{pre}/gt"] = np.int64(gt)
+            arrays[f"{pre}/tokens_pre"] = tree.tokens.numpy().copy()
+            arrays[f"{pre}/draft_logits_pre"] = tree.draft_logits[:n].numpy().copy()
+            for (lvl, ins, out) in samp_log:
+                arrays[f"{pre}/samp{lvl}/logits"] = ins[0]
+                if len(ins) > 1:
+                    arrays[f"{pre}/samp{lvl}/rand"] = ins[1]
+                arrays[f"{pre}/samp{lvl}/out"] = out
+            step_box["i"] = step
+            step_box["last_residual"] = None
+            # capture the raw target logits by wrapping the engine for one call
+            raw_box = {}
+            orig_inf = target.inference
+
+            def spy(**kw):
+                out = orig_inf(**kw)
+                raw_box["logits"] = out
+                return out
+            target.inference = spy
+            valid, a, _, terminal = tree.verify()
+            target.inference = orig_inf
+            tl = raw_box["logits"][0]
+            arrays[f"{pre}/target_logits"] = tl[-n:].numpy().copy() if tl.shape[0] >= n else tl.numpy().copy()
+            arrays[f"{pre}/valid_tokens"] = valid.numpy().copy()
+            arrays[f"{pre}/accept_len"] = np.int64(a)
+            arrays[f"{pre}/terminal"] = np.int64(int(terminal))
+            arrays[f"{pre}/tokens_post"] = tree.tokens.numpy().copy()
+            if step_box["last_residual"] is not None:
+                arrays[f"{pre}/residual"] = step_box["last_residual"]
+            arrays[f"{pre}/draft_logits_post"] = tree.draft_logits[:n].numpy().copy()
+            arrays[f"{pre}/kv_draft"] = kv_checksum(draft)
+            arrays[f"{pre}/kv_target"] = kv_checksum(target)
+            arrays[f"{pre}/position_ids_post"] = tree.position_ids.numpy().copy()
+            cur_len = valid.shape[0]
+            step += 1
+        arrays["n_steps"] = np.int64(step)
+        # final KV cache contents of the (small) draft cache, for exact compaction parity
+        arrays["final/draft_k"] = draft.engine.kv_cache.k_cache.numpy().copy()
+        arrays["final/target_k"] = target.engine.kv_cache.k_cache.numpy().copy()
+        arrays["final/target_v"] = target.engine.kv_cache.v_cache.numpy().copy()
+    finally:
+        torch.Tensor.multinomial = orig_multinomial
+
+    meta = dict(name=name, growmap=os.path.relpath(growmap_path, REF), draft_dims=list(draft_dims),
+                target_dims=list(target_dims), vocab=vocab, M=M, T=T, mode=mode, prompt_len=prompt_len,
+                seed=seed, logit_gain=logit_gain, share_weights=share_weights, n_tree=int(n),
+                successors=g["Successors"], torch=torch.__version__)
+    arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    out_dir = out_dir or os.path.join(REPO, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"trace_{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: steps={step} terminal={terminal} final_len={cur_len} -> {path} "
+          f"({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def gen_rows_fullvocab(R, out_dir):
+    """Single-row sampler / residual cases at the real vocabulary size (V = 32000) produced by
+    the reference's own functions (utils.py:5-18,29-32)."""
+    RU = R["RU"]
+    V = 32000
+    arrays = {}
+    torch.manual_seed(123)
+    for i, (gain, k) in enumerate([(2.0, 19), (5.0, 13), (9.0, 64), (1.0, 8)]):
+        logits = (torch.randn(2, V) * gain).half()
+        rand = torch.empty(2, V, dtype=torch.float16).uniform_()
+        arrays[f"wor{i}/logits"] = logits.numpy()
+        arrays[f"wor{i}/rand"] = rand.numpy()
+        arrays[f"wor{i}/k"] = np.int64(k)
+        arrays[f"wor{i}/out"] = RU.sampling_without_replacement(logits, rand, k, 0.6).numpy()
+        arrays[f"wor{i}/argmax_out"] = RU.sampling_argmax(logits, k).numpy()
+        p = torch.softmax(logits[0] / 0.6, dim=-1)
+        q = torch.softmax(logits[1] / 0.6, dim=-1)
+        arrays[f"wor{i}/residual"] = RU.get_residual(p, q).numpy()
+    path = os.path.join(out_dir, "rows_v32000.npz")
+    np.savez_compressed(path, **arrays)
+    print("rows ->", path, f"({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def main():
+    R = import_reference()
+    out_dir = os.path.join(REPO, "tests", "golden")
+    tiny = (64, 172, 2, 4, 4)       # hidden, inter, layers, heads, kv_heads  (D = 16)
+    tiny_t = (128, 344, 2, 4, 4)    # D = 32
+    gqa_t = (128, 344, 2, 8, 2)     # D = 16, GQA 4:1
+    gm = lambda p: os.path.join(REF, p)
+    # config A plumbing: 2-chain growmap, stochastic
+    run_case(R, "A_2chain", gm("L40_growmaps/2-chain.pt"), tiny, tiny_t, 1024, 96, 0.6, "stochastic", 16, 6, 17,
+             logit_gain=8.0, out_dir=out_dir)
+    # config B shape: 128-node Sequoia tree, correlated draft so that paths are non-trivial
+    run_case(R, "B_seq128", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), tiny_t, tiny_t, 1024,
+             256, 0.6, "stochastic", 24, 3, 18, logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
+    # small demo tree, uncorrelated draft, several steps
+    run_case(R, "demo4", gm("demo_tree.pt"), tiny, gqa_t, 1024, 96, 0.6, "stochastic", 12, 8, 19, out_dir=out_dir)
+    # config C: greedy 8x8 tree
+    run_case(R, "C_greedy8x8", gm("L40_growmaps/8x8-tree.pt"), tiny_t, tiny_t, 1024, 192, 0.6, "greedy", 20, 4, 20,
+             logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
+    # config E shape (64x2) stochastic with GQA target
+    run_case(R, "E_64x2", gm("L40_growmaps/64x2-tree.pt"), tiny, gqa_t, 1024, 224, 0.6, "stochastic", 16, 2, 21,
+             logit_gain=6.0, out_dir=out_dir)
+    gen_rows_fullvocab(R, out_dir)
+
+
+if __name__ == "__main__":
+    main()
