@@ -112,13 +112,20 @@ int sq_rope_kv_write_f16(const void* qkv, int qkv_stride, void* q_out,
  * q: fp16 [H][q_len][D]; out: fp16 [q_len][H*D] (the layout o_proj consumes).
  * mask_mode 0: dense additive fp16 mask [q_len][mask_stride] (the reference's attn_mask);
  * mask_mode 1: implicit tree mask = same rule as sq_tree_mask_dense_f16, query i sits at slot
- *              q_slot0 + i.                                                                 */
+ *              q_slot0 + i.
+ * d_ctx (optional, device int32[3]): when non-NULL the kernel takes {q_slot0, gt, kv_len} from
+ * it instead of the by-value arguments, so a captured launch can be replayed for other steps. */
 int sq_tree_attention_f16(const void* q, const void* k_layer, const void* v_layer, void* out,
                           int q_len, int n_heads, int h_kv, int d, int m, int kv_len,
                           float scale, int mask_mode,
                           const void* dense_mask, int mask_stride,
                           int q_slot0, int gt, int n_tree,
-                          const uint64_t* d_bitmask, int words, void* stream);
+                          const uint64_t* d_bitmask, int words, const int32_t* d_ctx,
+                          void* stream);
+
+/* Stream-ordered store of up to four int32 values into device memory (dst[0..n)); used to
+ * update a d_ctx block between graph replays without a host->device copy.                    */
+int sq_store_i32(int32_t* dst, int n, int v0, int v1, int v2, int v3, void* stream);
 
 /* ---- a2: draft expansion samplers ------------------------------------------------------- */
 /* utils.sampling_without_replacement (utils.py:10-18) for n_rows rows:
@@ -173,6 +180,19 @@ int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens,
                          const int32_t* d_child_off, const int32_t* d_child_ids,
                          int n_tree, int vocab, int gt, void* workspace, int32_t* d_result,
                          void* stream);
+
+/* ---- row-wise glue of the Llama block (launch removal on the draft side) --- */
+/* LlamaRMSNorm_FI.forward (Engine/Llama_modules.py:274-288): fp32 variance, normalised value
+ * cast to fp16, then fp16 multiply by the weight.  x, out: fp16 [rows][hidden].              */
+int sq_rmsnorm_f16(const void* x, const void* weight, void* out, int rows, int hidden, float eps,
+                   void* stream);
+/* residual add + RMSNorm of the decoder layer (Engine/Llama_modules.py:341-346):
+ * sum_out = x + residual (fp16 add; sum_out may alias residual), out = rmsnorm(sum_out)*weight */
+int sq_add_rmsnorm_f16(const void* x, const void* residual, void* sum_out, const void* weight,
+                       void* out, int rows, int hidden, float eps, void* stream);
+/* LlamaMLP_FI (Engine/Llama_modules.py:270-271): out = act_fn(gate) * up in fp16.
+ * gate_up: fp16 [rows][2*inter] packed gate | up (one fused GEMM); out: fp16 [rows][inter].  */
+int sq_silu_mul_f16(const void* gate_up, void* out, int rows, int inter, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,100 @@
+// Row-wise fused elementwise ops of the Llama block around the attention hot path: RMSNorm
+// (optionally fused with the residual add) and SiLU(gate)*up.  They exist to remove launches
+// from the launch-bound draft forward; each is one pass over the row with
+// 16-byte accesses.  Rounding points follow the reference's fp16/fp32 expression
+// (Engine/Llama_modules.py:274-288: fp32 variance, cast to fp16, fp16 multiply by the weight;
+// :271: act_fn(gate) * up in fp16).
+#include "common.h"
+
+#define ROW_THREADS 256
+#define ROW_WAVES (ROW_THREADS / 64)
+
+// x: [rows][hidden] fp16; optional residual add: h = x + res (fp16 add), h written back to res_out.
+template <bool ADD>
+__global__ void __launch_bounds__(ROW_THREADS)
+rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ res, half_t* __restrict__ sum_out,
+               const half_t* __restrict__ w, half_t* __restrict__ out, int hidden, float eps) {
+    __shared__ float s_f[ROW_WAVES];
+    const size_t row = blockIdx.x;
+    const half_t* xr = x + row * hidden;
+    const int chunks = hidden >> 3;
+    float ss = 0.f;
+    // pass 1: (optional add) + sum of squares; rows are small (<= 16 KB) and stay in L1/L2 for pass 2
+    for (int c = threadIdx.x; c < chunks; c += ROW_THREADS) {
+        half8 v = *(const half8*)(xr + c * 8);
+        if (ADD) {
+            const half8 r = *(const half8*)(res + row * hidden + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] + (float)r[j]);
+            *(half8*)(sum_out + row * hidden + c * 8) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+    }
+    const float tot = block_sum_f32<ROW_WAVES>(ss, s_f);
+    const float inv = rsqrtf(tot / (float)hidden + eps);
+    const half_t* src = ADD ? (const half_t*)(sum_out + row * hidden) : xr;
+    for (int c = threadIdx.x; c < chunks; c += ROW_THREADS) {
+        // ADD: re-read what this same thread wrote above (same c) -> program order suffices
+        const half8 v = *(const half8*)(src + c * 8);
+        const half8 wv = *(const half8*)(w + c * 8);
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const half_t n = (half_t)((float)v[j] * inv);
+            o[j] = (half_t)((float)wv[j] * (float)n);
+        }
+        *(half8*)(out + row * hidden + c * 8) = o;
+    }
+}
+
+extern "C" int sq_rmsnorm_f16(const void* x, const void* weight, void* out, int rows, int hidden, float eps,
+                              void* stream) {
+    if (!x || !weight || !out || rows < 0 || hidden <= 0) return SQ_EINVAL;
+    if (hidden & 7) return SQ_EUNSUPPORTED;
+    if (rows == 0) return SQ_OK;
+    hipLaunchKernelGGL((rmsnorm_kernel<false>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       (const half_t*)x, (const half_t*)nullptr, (half_t*)nullptr, (const half_t*)weight, (half_t*)out,
+                       hidden, eps);
+    return sq_check_launch();
+}
+
+// h = x + residual (written to sum_out, may alias residual), out = rmsnorm(h) * weight
+extern "C" int sq_add_rmsnorm_f16(const void* x, const void* residual, void* sum_out, const void* weight, void* out,
+                                   int rows, int hidden, float eps, void* stream) {
+    if (!x || !residual || !sum_out || !weight || !out || rows < 0 || hidden <= 0) return SQ_EINVAL;
+    if (hidden & 7) return SQ_EUNSUPPORTED;
+    if (rows == 0) return SQ_OK;
+    hipLaunchKernelGGL((rmsnorm_kernel<true>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       (const half_t*)x, (const half_t*)residual, (half_t*)sum_out, (const half_t*)weight,
+                       (half_t*)out, hidden, eps);
+    return sq_check_launch();
+}
+
+// gate_up: [rows][2*inter] (gate | up), out: [rows][inter];  out = h(h(silu(gate)) * up)
+__global__ void __launch_bounds__(ROW_THREADS)
+silu_mul_kernel(const half_t* __restrict__ gate_up, half_t* __restrict__ out, int inter) {
+    const size_t row = blockIdx.y;
+    const int c = blockIdx.x * ROW_THREADS + threadIdx.x;
+    if (c * 8 >= inter) return;
+    const half8 gv = *(const half8*)(gate_up + row * 2 * inter + c * 8);
+    const half8 uv = *(const half8*)(gate_up + row * 2 * inter + inter + c * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float gf = (float)gv[j];
+        const half_t s = (half_t)(gf / (1.0f + expf(-gf)));
+        o[j] = (half_t)((float)s * (float)uv[j]);
+    }
+    *(half8*)(out + row * inter + c * 8) = o;
+}
+
+extern "C" int sq_silu_mul_f16(const void* gate_up, void* out, int rows, int inter, void* stream) {
+    if (!gate_up || !out || rows < 0 || inter <= 0) return SQ_EINVAL;
+    if (inter & 7) return SQ_EUNSUPPORTED;
+    if (rows == 0) return SQ_OK;
+    const int chunks = inter >> 3;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((chunks + ROW_THREADS - 1) / ROW_THREADS, rows), dim3(ROW_THREADS), 0,
+                       (hipStream_t)stream, (const half_t*)gate_up, (half_t*)out, inter);
+    return sq_check_launch();
+}

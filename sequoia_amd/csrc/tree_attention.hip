@@ -1,0 +1,303 @@
+// a3/a4: tree-batched attention for one layer, MFMA (v_mfma_f32_16x16x32_f16) for both
+// contractions, fp32 online softmax, tree-causal mask evaluated from the ancestor bitmask
+// (no dense mask in HBM) or, for drop-in callers, from the reference's dense additive mask.
+//
+// Decomposition (latency-bound problem: per layer only ~6 MB of K/V/Q/O, 0.5 GFLOP):
+//   grid  = (ceil(q_len / 16), n_heads): one workgroup per (16-query tile, head) -> 256
+//           workgroups for the 7B verify (q = 128, H = 32), one per CU.
+//   block = 4 waves; wave w walks the 32-key chunks w, w+4, ... of the KV range (split-KV inside
+//           the workgroup) with its own online-softmax state, and the four partial results are
+//           merged through LDS at the end.
+// Per 32-key chunk and wave:
+//   S^T = K Q^T   (A = K rows straight from HBM as 16-byte fragment loads, B = Q, held in VGPRs)
+//         -> lane (q = lane&15, g = lane>>4) holds keys {16t + 4g + r}: exactly the A-operand
+//            layout the P V MFMA wants (k-slot 8g + j <-> key 16(j>>2) + 4g + (j&3)), so P never
+//            leaves registers.
+//   O  += P V     (B = V through a wave-private LDS tile, read back transposed with
+//                  ds_read_b64_tr_b16; the same key permutation is applied by construction).
+#include "common.h"
+#include <stdlib.h>
+
+#define ATT_WAVES 4
+#define ATT_THREADS (ATT_WAVES * 64)
+#define ATT_BM 16      // queries per workgroup
+#define ATT_BK 32      // keys per chunk
+
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+struct AttnParams {
+    const half_t* q;        // [H][q_len][D]
+    const half_t* k;        // [H_kv][M][D]
+    const half_t* v;        // [H_kv][M][D]
+    half_t* out;            // [q_len][H*D]
+    int q_len, n_heads, h_kv, m, kv_len;
+    float scale_log2e;      // scale * log2(e)
+    int mask_mode;          // 0 dense additive, 1 implicit tree
+    const half_t* dense;    // [q_len][mask_stride]
+    int mask_stride;
+    int q_slot0, gt, n_tree;
+    const uint64_t* bitmask;
+    int words;
+    const int32_t* ctx;     // optional device override of {q_slot0, gt, kv_len} (hipGraph replays)
+};
+
+template <int D, bool TR>
+__global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams P) {
+    if (P.ctx) {   // uniform: step-dependent scalars live in device memory so the launch is graph-replayable
+        P.q_slot0 = P.ctx[0]; P.gt = P.ctx[1]; P.kv_len = P.ctx[2];
+        if (P.kv_len > P.m) P.kv_len = P.m;
+        if (P.kv_len < 1) P.kv_len = 1;
+    }
+    constexpr int DSTEPS = D / 32;       // MFMA k-steps for S^T
+    constexpr int NT = D / 16;           // 16-wide output column tiles
+    constexpr int VSTRIDE = D + 8;       // halves; +16 B keeps ds_write_b128 aligned and de-phases banks
+    constexpr int V_TILE = ATT_BK * VSTRIDE;                    // halves per wave
+    constexpr int O_TILE = ATT_BM * D;                          // floats per wave
+    // LDS: V staging (per wave) is reused for the cross-wave merge of O.
+    constexpr int LDS_BYTES_V = ATT_WAVES * V_TILE * 2;
+    constexpr int LDS_BYTES_O = ATT_WAVES * O_TILE * 4;
+    constexpr int LDS_MAIN = LDS_BYTES_V > LDS_BYTES_O ? LDS_BYTES_V : LDS_BYTES_O;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_MAIN + ATT_WAVES * ATT_BM * 8 + ATT_BM * 8 * SQ_MAX_TREE / 64];
+    half_t* lds_v = (half_t*)lds_raw;
+    float* lds_o = (float*)lds_raw;
+    float* lds_ml = (float*)(lds_raw + LDS_MAIN);                          // [wave][16][2] (m, l)
+    uint64_t* lds_bm = (uint64_t*)(lds_raw + LDS_MAIN + ATT_WAVES * ATT_BM * 8);  // [16][words]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int qc = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * ATT_BM;
+    const int head = blockIdx.y;
+    const int kvh = head / (P.n_heads / P.h_kv);
+    const half_t* kbase = P.k + (size_t)kvh * P.m * D;
+    const half_t* vbase = P.v + (size_t)kvh * P.m * D;
+
+    // this lane's query row (softmax side): q0 + qc
+    const int qi = q0 + qc;
+    const bool q_valid = qi < P.q_len;
+    const int qi_c = q_valid ? qi : P.q_len - 1;
+    const int slot = P.q_slot0 + qi_c;
+    const int tnode = slot - (P.gt - 1);
+
+    if (P.mask_mode == 1) {
+        // stage the ancestor-bitmask rows of the 16 queries
+        for (int i = tid; i < ATT_BM * P.words; i += ATT_THREADS) {
+            const int r = i / P.words, w = i - r * P.words;
+            int qq = q0 + r; if (qq >= P.q_len) qq = P.q_len - 1;
+            const int tn = P.q_slot0 + qq - (P.gt - 1);
+            lds_bm[i] = (tn >= 1 && tn < P.n_tree) ? P.bitmask[(size_t)tn * P.words + w] : 0ull;
+        }
+    }
+
+    // Q fragments (B operand): lane (n = qc, g) holds Q[qi][32*s + 8*g .. +8]
+    half8 qf[DSTEPS];
+    {
+        const half_t* qrow = P.q + ((size_t)head * P.q_len + qi_c) * D;
+#pragma unroll
+        for (int s = 0; s < DSTEPS; ++s) qf[s] = *(const half8*)(qrow + s * 32 + g * 8);
+    }
+    __syncthreads();
+
+    float m_run = -INFINITY, l_run = 0.f;
+    floatx4 o_acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) o_acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    half_t* my_v = lds_v + wave * V_TILE;
+    const int n_chunks = (P.kv_len + ATT_BK - 1) / ATT_BK;
+    for (int ch = wave; ch < n_chunks; ch += ATT_WAVES) {
+        const int key0 = ch * ATT_BK;
+        // ---- V chunk -> LDS (row-major, padded) -----------------------------------------------
+        {
+            constexpr int CPR = D / 8;                      // 16-byte chunks per row
+            constexpr int ITER = ATT_BK * CPR / 64;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int idx = it * 64 + lane;
+                const int r = idx / CPR, c = idx % CPR;
+                int kr = key0 + r; if (kr >= P.kv_len) kr = P.kv_len - 1;
+                const u32x4 val = *(const u32x4*)(vbase + (size_t)kr * D + c * 8);
+                *(u32x4*)(my_v + r * VSTRIDE + c * 8) = val;
+            }
+        }
+        // ---- S^T = K Q^T ------------------------------------------------------------------------
+        floatx4 s_acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int kr = key0 + t * 16 + qc; if (kr >= P.kv_len) kr = P.kv_len - 1;
+            const half_t* krow = kbase + (size_t)kr * D;
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < DSTEPS; ++s) {
+                const half8 kf = *(const half8*)(krow + s * 32 + g * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], acc, 0, 0, 0);
+            }
+            s_acc[t] = acc;
+        }
+        // ---- mask + online softmax (this lane: query qc, keys key0 + 16t + 4g + r) -----------------
+        float sv[8];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + t * 16 + g * 4 + r;
+                float x = s_acc[t][r] * P.scale_log2e;
+                bool vis = key < P.kv_len;
+                if (P.mask_mode == 1) {
+                    if (vis) {
+                        if (slot < P.gt) vis = key <= slot;
+                        else if (key >= P.gt) {
+                            const int j = key - (P.gt - 1);
+                            vis = (tnode < P.n_tree) && (j < P.n_tree) &&
+                                  ((lds_bm[qc * P.words + (j >> 6)] >> (j & 63)) & 1ull);
+                        }
+                    }
+                    if (!vis) x = -INFINITY;
+                } else {
+                    if (vis) x += (float)P.dense[(size_t)qi_c * P.mask_stride + key] * 1.4426950408889634f;
+                    else x = -INFINITY;
+                }
+                sv[t * 4 + r] = x;
+                cmax = fmaxf(cmax, x);
+            }
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float m_new = fmaxf(m_run, cmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;      // fully masked so far
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // exp2(-inf) = 0 on the first chunk
+        half8 pf;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = __builtin_amdgcn_exp2f(sv[j] - m_use);
+            psum += p;
+            pf[j] = (half_t)p;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // O rows are q = 4g + r: fetch their alphas from the lanes that own those queries
+        float a4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a4[r] = __shfl(alpha, g * 4 + r, 64);
+        // ---- O += P V ---------------------------------------------------------------------------
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // B fragment: k-slot 8g + j  <->  key row 16(j>>2) + 4g + (j&3), column 16nt + qc.
+            // ds_read_b64_tr_b16: lane i of a 16-lane group supplies 4 contiguous halves of row
+            // (i>>2), columns 4(i&3).., and receives column i of the group's 4x16 block.
+            const half_t* a0 = my_v + (0 * 16 + g * 4 + (qc >> 2)) * VSTRIDE + nt * 16 + (qc & 3) * 4;
+            const half_t* a1 = my_v + (1 * 16 + g * 4 + (qc >> 2)) * VSTRIDE + nt * 16 + (qc & 3) * 4;
+            half8 vf;
+            if constexpr (TR) {
+                const fp16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
+                const fp16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vf[j] = (half_t)b0[j]; vf[4 + j] = (half_t)b1[j]; }
+            } else {
+                // plain 2-byte gathers (debug / fallback variant, SQ_ATTN_NO_TR=1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    vf[j] = my_v[((j >> 2) * 16 + g * 4 + (j & 3)) * VSTRIDE + nt * 16 + qc];
+            }
+            floatx4 o = o_acc[nt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= a4[r];
+            o_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- merge the four waves ---------------------------------------------------------------------
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();                       // everyone is done with the V staging area
+    if (g == 0) { lds_ml[(wave * ATT_BM + qc) * 2] = m_run; lds_ml[(wave * ATT_BM + qc) * 2 + 1] = l_run; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            lds_o[(wave * ATT_BM + g * 4 + r) * D + nt * 16 + qc] = o_acc[nt][r];
+    __syncthreads();
+    {
+        constexpr int EPT_O = ATT_BM * D / ATT_THREADS;       // 8 (D=128) or 4 (D=64)
+        const int row = tid / (D / EPT_O);
+        const int col = (tid % (D / EPT_O)) * EPT_O;
+        float mw[ATT_WAVES], lw[ATT_WAVES], mmax = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) {
+            mw[w] = lds_ml[(w * ATT_BM + row) * 2];
+            lw[w] = lds_ml[(w * ATT_BM + row) * 2 + 1];
+            mmax = fmaxf(mmax, mw[w]);
+        }
+        float denom = 0.f, wgt[ATT_WAVES];
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) {
+            wgt[w] = (mw[w] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[w] - mmax);
+            denom += lw[w] * wgt[w];
+        }
+        const float inv = denom > 0.f ? 1.0f / denom : 0.f;
+        if (q0 + row < P.q_len) {
+            half_t* dst = P.out + (size_t)(q0 + row) * (P.n_heads * D) + head * D + col;
+            float res[EPT_O];
+#pragma unroll
+            for (int e = 0; e < EPT_O; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < ATT_WAVES; ++w) acc += lds_o[(w * ATT_BM + row) * D + col + e] * wgt[w];
+                res[e] = acc * inv;
+            }
+            if constexpr (EPT_O == 8) {
+                half8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = (half_t)res[e];
+                *(half8*)dst = o8;
+            } else {
+                half4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (half_t)res[e];
+                *(half4*)dst = o4;
+            }
+        }
+    }
+}
+
+extern "C" int sq_tree_attention_f16(const void* q, const void* k_layer, const void* v_layer, void* out, int q_len,
+                                     int n_heads, int h_kv, int d, int m, int kv_len, float scale, int mask_mode,
+                                     const void* dense_mask, int mask_stride, int q_slot0, int gt, int n_tree,
+                                     const uint64_t* d_bitmask, int words, const int32_t* d_ctx, void* stream) {
+    if (!q || !k_layer || !v_layer || !out || q_len < 0 || n_heads <= 0 || h_kv <= 0 || m <= 0) return SQ_EINVAL;
+    if (d_ctx) { if (kv_len <= 0) kv_len = 1; if (gt < 1) gt = 1; }
+    if (kv_len <= 0 || kv_len > m || n_heads % h_kv) return SQ_EINVAL;
+    if (d != 64 && d != 128) return SQ_EUNSUPPORTED;
+    AttnParams P;
+    P.q = (const half_t*)q; P.k = (const half_t*)k_layer; P.v = (const half_t*)v_layer; P.out = (half_t*)out;
+    P.q_len = q_len; P.n_heads = n_heads; P.h_kv = h_kv; P.m = m; P.kv_len = kv_len;
+    P.scale_log2e = scale * 1.4426950408889634f;
+    P.mask_mode = mask_mode;
+    P.dense = (const half_t*)dense_mask; P.mask_stride = mask_stride;
+    P.q_slot0 = q_slot0; P.gt = gt; P.n_tree = n_tree; P.bitmask = d_bitmask; P.words = words; P.ctx = d_ctx;
+    if (mask_mode == 0) {
+        if (!dense_mask || mask_stride < kv_len) return SQ_EINVAL;
+    } else if (mask_mode == 1) {
+        if (gt < 1 || n_tree < 1 || n_tree > SQ_MAX_TREE) return SQ_EINVAL;
+        if (n_tree > 1 && (!d_bitmask || words < SQ_MASK_WORDS(n_tree) || words > SQ_MAX_TREE / 64)) return SQ_EINVAL;
+        if (n_tree == 1) { P.words = words > 0 ? words : 1; }
+    } else {
+        return SQ_EINVAL;
+    }
+    if (q_len == 0) return SQ_OK;
+    dim3 grid((q_len + ATT_BM - 1) / ATT_BM, n_heads), block(ATT_THREADS);
+    static const bool no_tr = getenv("SQ_ATTN_NO_TR") != nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 128) {
+        if (no_tr) hipLaunchKernelGGL((tree_attention_kernel<128, false>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((tree_attention_kernel<128, true>), grid, block, 0, st, P);
+    } else {
+        if (no_tr) hipLaunchKernelGGL((tree_attention_kernel<64, false>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((tree_attention_kernel<64, true>), grid, block, 0, st, P);
+    }
+    return sq_check_launch();
+}

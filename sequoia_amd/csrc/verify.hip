@@ -1,0 +1,369 @@
+// a6/a7/a8: verification.  Two launches on the caller's stream:
+//   1. verify_nodes: one 1024-thread workgroup per tree node, all nodes in parallel.  Node t reads
+//      its target-logits row once and (internal nodes) its draft-logits row once -- the
+//      algorithmic byte count (n + n_internal) * V * 2 of SURVEY.md §8(d) -- and evaluates
+//      accept_step (Tree/SpecTree.py:136-157) for its own children speculatively: first
+//      accepted child, or the residual distribution and the bonus token drawn from it.
+//   2. verify_walk: one wave follows node -> accepted child from the root (longest accepted
+//      path), applies the reference's side effects along the walked path only, and fills the
+//      result record.  No host synchronisation anywhere.
+// The fp16 rounding points are those of the reference's fp16 tensor expressions (see
+// oracle/ops_np.py); the residual normaliser and the inverse CDF are exact integer sums on the
+// 2^-24 grid, so they are independent of reduction order.
+#include "common.h"
+
+#define VER_THREADS 1024
+#define VER_WAVES (VER_THREADS / 64)
+
+struct VerifyWs {
+    int32_t* child;   // [n] tree id of the first accepted child, -1 if none
+    int32_t* bonus;   // [n] token drawn from the node's final distribution (valid when child == -1)
+    int32_t* flag;    // [n] 1 = residual is NaN
+    int32_t* nrej;    // [n] number of rejected children (= index of the accepted one)
+    int32_t* path;    // [n] tree ids of the accepted path (written by the walker)
+    int64_t* tgt;     // [n] greedy: target argmax
+};
+__host__ __device__ static inline VerifyWs ws_layout(void* ws, int n) {
+    VerifyWs w;
+    int32_t* p = (int32_t*)ws;
+    w.child = p; w.bonus = p + n; w.flag = p + 2 * n; w.nrej = p + 3 * n; w.path = p + 4 * n;
+    w.tgt = (int64_t*)(p + 5 * n + (n & 1));
+    return w;
+}
+extern "C" size_t sq_verify_workspace_bytes(int n_tree) {
+    if (n_tree <= 0) return 0;
+    return (size_t)(5 * n_tree + (n_tree & 1)) * 4 + (size_t)n_tree * 8 + 64;
+}
+
+__device__ __forceinline__ int v_elem(int c, int t, int j) { return (c * VER_THREADS + t) * 8 + j; }
+
+// exact round-to-nearest-even of total * 2^-24 to fp16 (total is an exact integer sum)
+__device__ __forceinline__ half_t grid_sum_to_f16(unsigned long long total) {
+    if (total == 0ull) return (half_t)0.0f;
+    const int hb = 63 - __clzll((long long)total);
+    if (hb <= 10) return (half_t)((float)(uint32_t)total * 5.9604644775390625e-08f);  // exact
+    const int shift = hb - 10;
+    unsigned long long q = total >> shift;
+    const unsigned long long rem = total & ((1ull << shift) - 1ull);
+    const unsigned long long halfway = 1ull << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1ull))) q += 1ull;
+    return (half_t)ldexpf((float)(uint32_t)q, shift - 24);
+}
+
+// softmax(x / T) with the reference's rounding: returns h(exp(y - max) / sum) per element
+template <int EPT>
+__device__ __forceinline__ void row_softmax_f16(const half_t* __restrict__ x, int vocab, float temperature, int t,
+                                                half_t (&p)[EPT], float* s_f) {
+    float y[EPT];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < EPT / 8; ++c) {
+        const int e0 = v_elem(c, t, 0);
+        half8 v;
+        if (e0 < vocab) v = *(const half8*)(x + e0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float yy = -INFINITY;
+            if (e0 + j < vocab) yy = (float)(half_t)((float)v[j] / temperature);
+            y[c * 8 + j] = yy;
+            lmax = fmaxf(lmax, yy);
+        }
+    }
+    const float mx = block_max_f32<VER_WAVES>(lmax, s_f);
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        y[i] = expf(y[i] - mx);
+        lsum += y[i];
+    }
+    const float z = block_sum_f32<VER_WAVES>(lsum, s_f);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) p[i] = (half_t)(y[i] / z);
+}
+
+template <int EPT>
+__global__ void __launch_bounds__(VER_THREADS)
+verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __restrict__ draft_logits,
+                    const int64_t* __restrict__ tokens, const half_t* __restrict__ r16,
+                    const int32_t* __restrict__ child_off, const int32_t* __restrict__ child_ids, int n_tree,
+                    int vocab, int gt, float temperature, uint32_t u24, void* ws_raw) {
+    constexpr int CH = EPT / 8;
+    __shared__ float s_f[VER_WAVES];
+    __shared__ unsigned long long s_u[VER_WAVES];
+    __shared__ float s_tok[2];            // e[tok], p[tok] of the child under test
+    __shared__ unsigned long long s_scan[VER_WAVES];
+    __shared__ int s_bonus;
+    const int t = threadIdx.x;
+    const int node = blockIdx.x;
+    const VerifyWs ws = ws_layout(ws_raw, n_tree);
+
+    half_t p[EPT];
+    row_softmax_f16<EPT>(target_logits + (size_t)node * vocab, vocab, temperature, t, p, s_f);
+
+    const int c0 = child_off[node], nc = child_off[node + 1] - c0;
+    int accepted = -1, nrej = 0, nan_flag = 0;
+    if (nc > 0) {
+        half_t yd[EPT];                   // h(draft_logits / T); rejected tokens become -inf
+        const half_t* xd = draft_logits + (size_t)node * vocab;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int e0 = v_elem(c, t, 0);
+            half8 v;
+            if (e0 < vocab) v = *(const half8*)(xd + e0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                yd[c * 8 + j] = (e0 + j < vocab) ? (half_t)((float)v[j] / temperature) : (half_t)(-INFINITY);
+        }
+        for (int jc = 0; jc < nc; ++jc) {
+            const int child = child_ids[c0 + jc];
+            const int slot = child + gt - 1;
+            const int tok = (int)tokens[slot];
+            const half_t rr = r16[slot];
+            // q = softmax(yd): max, exp, sum
+            float lmax = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) lmax = fmaxf(lmax, (float)yd[i]);
+            const float mx = block_max_f32<VER_WAVES>(lmax, s_f);
+            float e[EPT];
+            float lsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                e[i] = expf((float)yd[i] - mx);
+                lsum += e[i];
+                if (v_elem(i >> 3, t, i & 7) == tok) { s_tok[0] = e[i]; s_tok[1] = (float)p[i]; }
+            }
+            const float z = block_sum_f32<VER_WAVES>(lsum, s_f);   // barriers inside publish s_tok
+            const half_t q_tok = (half_t)(s_tok[0] / z);
+            const half_t p_tok = (half_t)s_tok[1];
+            const half_t rq = (half_t)((float)rr * (float)q_tok);
+            const bool ok = (tok >= 0 && tok < vocab) && (p_tok > rq);   // strict, Tree/SpecTree.py:152
+            if (ok) { accepted = child; break; }
+            // reject: p <- relu(p - q) / sum(relu(p - q));  draft_logits[tok] <- -65504 (=> q[tok] = 0)
+            unsigned long long lint = 0ull;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const half_t q = (half_t)(e[i] / z);
+                half_t di = (half_t)((float)p[i] - (float)q);
+                di = di > (half_t)0.0f ? di : (half_t)0.0f;      // relu_; NaN p stays out (compares false)
+                p[i] = di;                                       // p now holds the unnormalised residual
+                lint += (unsigned long long)(uint32_t)((float)di * 16777216.0f);
+                if (v_elem(i >> 3, t, i & 7) == tok) yd[i] = (half_t)(-INFINITY);
+            }
+            const unsigned long long tot = block_sum_u64<VER_WAVES>(lint, s_u);
+            const half_t s16 = grid_sum_to_f16(tot);
+            if (tot == 0ull) nan_flag = 1;                       // 0/0 -> NaN residual (utils.py:7)
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) p[i] = (half_t)((float)p[i] / (float)s16);
+            nrej = jc + 1;
+            if (nan_flag) break;          // every later comparison with NaN is false: all rejected
+        }
+        if (nan_flag) nrej = nc;
+    }
+
+    int bonus = -1;
+    if (accepted < 0 && !nan_flag) {
+        // exact inverse CDF on the 2^-24 grid, element-index order = (chunk, thread, j)
+        unsigned long long csum[CH];
+        unsigned long long total = 0ull, base = 0ull;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            unsigned long long s = 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (v_elem(c, t, j) < vocab) s += (unsigned long long)(uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+            csum[c] = s;
+        }
+        unsigned long long ctot[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { ctot[c] = block_sum_u64<VER_WAVES>(csum[c], s_u); total += ctot[c]; }
+        if (total > 0ull) {
+            const unsigned long long thr = (__umul64hi((unsigned long long)u24, total) << 40) |
+                                           (((unsigned long long)u24 * total) >> 24);
+            int cstar = CH - 1;
+            unsigned long long run = 0ull;
+            bool found = false;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (!found && run + ctot[c] > thr) { cstar = c; base = run; found = true; }
+                run += ctot[c];
+            }
+            unsigned long long mine = 0ull;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) if (c == cstar) mine = csum[c];
+            // inclusive scan of `mine` over the 1024 threads
+            unsigned long long inc = mine;
+            const int lane = t & 63, w = t >> 6;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, o, 64);
+                uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), o, 64);
+                if (lane >= o) inc += ((unsigned long long)hi << 32) | lo;
+            }
+            if (lane == 63) s_scan[w] = inc;
+            if (t == 0) s_bonus = -1;
+            __syncthreads();
+            unsigned long long woff = 0ull;
+            for (int i = 0; i < w; ++i) woff += s_scan[i];
+            const unsigned long long excl = base + woff + inc - mine;
+            if (mine > 0ull && excl <= thr && thr < excl + mine) {
+                unsigned long long acc = excl;
+                int pick = -1;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if (c == cstar) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            acc += (unsigned long long)(uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+                            if (pick < 0 && acc > thr) pick = v_elem(c, t, j);
+                        }
+                    }
+                }
+                s_bonus = pick;
+            }
+            __syncthreads();
+            bonus = s_bonus;
+        }
+        if (bonus < 0) nan_flag = 1;      // empty distribution: treated like the NaN residual
+    }
+    if (t == 0) {
+        ws.child[node] = accepted;
+        ws.bonus[node] = bonus;
+        ws.flag[node] = nan_flag;
+        ws.nrej[node] = nrej;
+    }
+}
+
+// One wave.  Walk root -> accepted children; side effects of Tree/SpecTree.py:156,222,224.
+__global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const int32_t* __restrict__ child_off,
+                                   const int32_t* __restrict__ child_ids, int n_tree, int vocab, int gt,
+                                   void* ws_raw, int32_t* result, int greedy) {
+    const VerifyWs ws = ws_layout(ws_raw, n_tree);
+    if (threadIdx.x != 0) return;
+    int node = 0, n_acc = 0, terminal = 0, reason = 0;
+    for (int guard = 0; guard < n_tree; ++guard) {
+        int child = -1, nrej = 0;
+        const int c0 = child_off[node], nc = child_off[node + 1] - c0;
+        if (greedy) {
+            const int64_t want = ws.tgt[node];
+            for (int j = 0; j < nc; ++j) {
+                const int c = child_ids[c0 + j];
+                if (tokens[c + gt - 1] == want) { child = c; break; }
+            }
+        } else {
+            child = ws.child[node];
+            nrej = ws.nrej[node];
+            // draft_logits[node][token of every rejected child] = finfo(fp16).min
+            for (int j = 0; j < nrej && j < nc; ++j) {
+                const int64_t tok = tokens[child_ids[c0 + j] + gt - 1];
+                if (tok >= 0 && tok < vocab) draft_logits[(size_t)node * vocab + tok] = (half_t)(-65504.0f);
+            }
+        }
+        if (child < 0) break;
+        node = child;
+        ws.path[n_acc] = node;
+        if (n_acc < SQ_RESULT_INTS - SQ_RES_SLOTS) result[SQ_RES_SLOTS + n_acc] = node + gt - 1;
+        ++n_acc;
+        const int64_t tk = tokens[node + gt - 1];
+        if (tk == 0 || tk == 2) { terminal = 1; reason = 1; break; }   // Tree/SpecTree.py:208
+    }
+    int bonus = -1;
+    if (!terminal) {
+        if (greedy) {
+            bonus = (int)ws.tgt[node];
+        } else if (ws.flag[node]) {
+            terminal = 1; reason = 2;                                   // isnan(residual), :219
+        } else {
+            bonus = ws.bonus[node];
+        }
+    }
+    // tokens[:a] = tokens[accept_list]: slots ascending and dst <= src, so the sequential
+    // in-place move never overwrites a source it still needs.
+    for (int j = 0; j < n_acc; ++j) tokens[gt + j] = tokens[ws.path[j] + gt - 1];
+    const int a = gt + n_acc;
+    if (!terminal) tokens[a] = bonus;
+    result[SQ_RES_ACCEPT_LEN] = a;
+    result[SQ_RES_N_TREE] = n_acc;
+    result[SQ_RES_BONUS] = bonus;
+    result[SQ_RES_TERMINAL] = terminal;
+    result[SQ_RES_REASON] = reason;
+    result[SQ_RES_GT] = gt;
+    result[SQ_RES_LAST_NODE] = node;
+    result[7] = 0;
+}
+
+extern "C" int sq_verify_stochastic_f16(const void* target_logits, void* draft_logits, int64_t* tokens, const void* r,
+                                        const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab,
+                                        int gt, float temperature, uint32_t bonus_u24, void* workspace,
+                                        int32_t* d_result, void* stream) {
+    if (!target_logits || !draft_logits || !tokens || !r || !d_child_off || !workspace || !d_result) return SQ_EINVAL;
+    if (n_tree <= 0 || n_tree > SQ_MAX_TREE || vocab <= 0 || gt < 1 || !(temperature > 0.f)) return SQ_EINVAL;
+    if (n_tree > 1 && !d_child_ids) return SQ_EINVAL;
+    if ((vocab & 7) || ((uintptr_t)target_logits & 15) || ((uintptr_t)draft_logits & 15)) return SQ_EUNSUPPORTED;
+    if (bonus_u24 >= (1u << 24)) return SQ_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(n_tree), b(VER_THREADS);
+#define SQ_LAUNCH(EPT)                                                                                          \
+    hipLaunchKernelGGL((verify_nodes_kernel<EPT>), g, b, 0, st, (const half_t*)target_logits,                    \
+                       (const half_t*)draft_logits, (const int64_t*)tokens, (const half_t*)r, d_child_off,        \
+                       d_child_ids, n_tree, vocab, gt, temperature, bonus_u24, workspace)
+    if (vocab <= 8 * VER_THREADS) SQ_LAUNCH(8);
+    else if (vocab <= 32 * VER_THREADS) SQ_LAUNCH(32);
+    else return SQ_EUNSUPPORTED;
+#undef SQ_LAUNCH
+    int rc = sq_check_launch();
+    if (rc != SQ_OK) return rc;
+    hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, st, (half_t*)draft_logits, tokens, d_child_off,
+                       d_child_ids, n_tree, vocab, gt, workspace, d_result, 0);
+    return sq_check_launch();
+}
+
+// greedy: argmax per node (ties -> lowest id), then the same walker with token equality
+template <int EPT>
+__global__ void __launch_bounds__(VER_THREADS)
+argmax_rows_kernel(const half_t* __restrict__ logits, int vocab, int n_tree, void* ws_raw) {
+    __shared__ unsigned long long s_b[VER_WAVES];
+    const int t = threadIdx.x;
+    const half_t* x = logits + (size_t)blockIdx.x * vocab;
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int c = 0; c < EPT / 8; ++c) {
+        const int e0 = v_elem(c, t, 0);
+        if (e0 < vocab) {
+            const half8 v = *(const half8*)(x + e0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // NaN must not win an argmax used as a token id: order it lowest
+                const half_t val = v[j];
+                const uint32_t ord = (val != val) ? 0u : f16_to_ordered(val);
+                const unsigned long long comp = ((unsigned long long)(ord + 1u) << 32) | (uint32_t)(0xffffffffu - (uint32_t)(e0 + j));
+                best = comp > best ? comp : best;
+            }
+        }
+    }
+    const unsigned long long win = block_max_u64<VER_WAVES>(best, s_b);
+    if (t == 0) ws_layout(ws_raw, n_tree).tgt[blockIdx.x] = (int64_t)(0xffffffffu - (uint32_t)(win & 0xffffffffu));
+}
+
+extern "C" int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens, const int32_t* d_child_off,
+                                    const int32_t* d_child_ids, int n_tree, int vocab, int gt, void* workspace,
+                                    int32_t* d_result, void* stream) {
+    if (!target_logits || !tokens || !d_child_off || !workspace || !d_result) return SQ_EINVAL;
+    if (n_tree <= 0 || n_tree > SQ_MAX_TREE || vocab <= 0 || gt < 1) return SQ_EINVAL;
+    if (n_tree > 1 && !d_child_ids) return SQ_EINVAL;
+    if ((vocab & 7) || ((uintptr_t)target_logits & 15)) return SQ_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(n_tree), b(VER_THREADS);
+    if (vocab <= 8 * VER_THREADS)
+        hipLaunchKernelGGL((argmax_rows_kernel<8>), g, b, 0, st, (const half_t*)target_logits, vocab, n_tree, workspace);
+    else if (vocab <= 32 * VER_THREADS)
+        hipLaunchKernelGGL((argmax_rows_kernel<32>), g, b, 0, st, (const half_t*)target_logits, vocab, n_tree, workspace);
+    else if (vocab <= 128 * VER_THREADS)
+        hipLaunchKernelGGL((argmax_rows_kernel<128>), g, b, 0, st, (const half_t*)target_logits, vocab, n_tree, workspace);
+    else
+        return SQ_EUNSUPPORTED;
+    int rc = sq_check_launch();
+    if (rc != SQ_OK) return rc;
+    hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, st, (half_t*)nullptr, tokens, d_child_off, d_child_ids,
+                       n_tree, vocab, gt, workspace, d_result, 1);
+    return sq_check_launch();
+}

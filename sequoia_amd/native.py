@@ -1,0 +1,84 @@
+"""ctypes binding of libsequoia_hip.so (the C ABI declared in include/sequoia_hip.h).
+
+No torch types cross this boundary: callers pass raw device pointers (tensor.data_ptr()) and
+sizes.  The library must exist; there is no fallback.  `load()` raises if it is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libsequoia_hip.so")
+
+SQ_OK, SQ_EINVAL, SQ_EUNSUPPORTED, SQ_ELAUNCH = 0, -1, -2, -3
+SQ_MAX_TREE = 512
+SQ_MAX_TOPK = 128
+SQ_RESULT_INTS = 64
+SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_BONUS, SQ_RES_TERMINAL = 0, 1, 2, 3
+SQ_RES_REASON, SQ_RES_GT, SQ_RES_LAST_NODE, SQ_RES_SLOTS = 4, 5, 6, 8
+
+_vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+
+# name -> (restype, argtypes); mirrors include/sequoia_hip.h one to one
+PROTOTYPES = {
+    "sq_version": (_i, []),
+    "sq_last_error": (C.c_char_p, []),
+    "sq_device_ready": (_i, []),
+    "sq_tree_bitmask_from_successors": (_i, [_vp, _vp, _i, _vp, _i]),
+    "sq_tree_mask_dense_f16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "sq_kv_scatter_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sq_kv_compact_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "sq_kv_clear_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sq_rope_kv_write_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sq_tree_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _i, _i, _i,
+                                   _vp, _i, _vp, _vp]),
+    "sq_store_i32": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "sq_sample_wor_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "sq_topk_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sq_verify_workspace_bytes": (C.c_size_t, [_i]),
+    "sq_verify_stochastic_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp]),
+    "sq_verify_greedy_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sq_rmsnorm_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "sq_silu_mul_f16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sq_add_rmsnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+}
+
+_lib = None
+
+
+class SequoiaNativeError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises SequoiaNativeError when it is absent: the
+    product path never substitutes another implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SequoiaNativeError(
+            f"{LIB_PATH} not found: build it with `python -m sequoia_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no non-HIP fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # header / library drift
+            raise SequoiaNativeError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == SQ_OK:
+        return
+    msg = {SQ_EINVAL: "invalid argument", SQ_EUNSUPPORTED: "unsupported shape", SQ_ELAUNCH: "HIP launch error"}.get(
+        rc, f"error {rc}")
+    detail = ""
+    if rc == SQ_ELAUNCH and _lib is not None:
+        detail = ": " + (_lib.sq_last_error() or b"").decode()
+    raise SequoiaNativeError(f"{what}: {msg}{detail}")

@@ -1,0 +1,221 @@
+"""Torch-tensor front end of the C ABI: marshals tensors to raw pointers and launches on the
+current HIP stream.  PyTorch is plumbing here (device memory + streams); all compute is in
+libsequoia_hip.so.
+
+`get_ops()` returns the process-wide HipOps instance.  It raises when the library is missing
+or a tensor is not on a HIP device: the product path has no CPU implementation.  Tests may
+install a checker implementation with `set_ops_for_testing()` (the numpy oracle adapter in
+oracle/ops_adapter.py) to exercise the *host logic* on CPU; nothing in this package does.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import native
+from .native import check
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if t.device.type != "cuda":
+        raise native.SequoiaNativeError(
+            f"{name} lives on {t.device}: the Sequoia hot path only runs on a HIP device (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = native.load()
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- a1 ---------------------------------------------------------------------------------
+    def tree_mask_dense(self, out, q_slot0, gt, n_tree, bitmask):
+        _need(out, torch.float16, "out", contiguous=False)
+        assert out.dim() == 2 and out.stride(1) == 1
+        words = 0
+        if bitmask is not None:
+            _need(bitmask, torch.int64, "bitmask")
+            words = bitmask.shape[1]
+        check(self.lib.sq_tree_mask_dense_f16(out.data_ptr(), out.stride(0), out.shape[1], q_slot0, out.shape[0], gt,
+                                              n_tree, _ptr(bitmask), words, self._stream()), "sq_tree_mask_dense_f16")
+        return out
+
+    # ---- a5 ---------------------------------------------------------------------------------
+    def kv_scatter(self, k_layer, v_layer, new_k, new_v, storage_ids):
+        _need(k_layer, torch.float16, "k_layer"); _need(v_layer, torch.float16, "v_layer")
+        _need(new_k, torch.float16, "new_k"); _need(new_v, torch.float16, "new_v")
+        _need(storage_ids, torch.int64, "storage_ids")
+        h_kv, m, d = k_layer.shape[-3:]
+        q_len = storage_ids.shape[0]
+        check(self.lib.sq_kv_scatter_f16(k_layer.data_ptr(), v_layer.data_ptr(), new_k.data_ptr(), new_v.data_ptr(),
+                                         storage_ids.data_ptr(), q_len, h_kv, m, d, self._stream()), "sq_kv_scatter_f16")
+
+    def kv_compact(self, k_cache, v_cache, slots, count, max_count, dst_offset, zero_end):
+        """k_cache/v_cache: [L, 1, H, M, D]; slots: int32 device tensor; count: int32[1] device tensor or None."""
+        _need(k_cache, torch.float16, "k_cache"); _need(v_cache, torch.float16, "v_cache")
+        if max_count > 0:
+            _need(slots, torch.int32, "slots")
+        if count is not None:
+            _need(count, torch.int32, "count", contiguous=False)
+        n_layers = k_cache.shape[0]
+        h_kv, m, d = k_cache.shape[-3:]
+        check(self.lib.sq_kv_compact_f16(k_cache.data_ptr(), v_cache.data_ptr(), n_layers, h_kv, m, d, _ptr(slots),
+                                         _ptr(count), max_count, dst_offset, zero_end, self._stream()),
+              "sq_kv_compact_f16")
+
+    def kv_clear(self, k_cache, v_cache, used_rows):
+        _need(k_cache, torch.float16, "k_cache"); _need(v_cache, torch.float16, "v_cache")
+        n_layers = k_cache.shape[0]
+        h_kv, m, d = k_cache.shape[-3:]
+        check(self.lib.sq_kv_clear_f16(k_cache.data_ptr(), v_cache.data_ptr(), n_layers, h_kv, m, d, used_rows,
+                                       self._stream()), "sq_kv_clear_f16")
+
+    # ---- a3 / a4 ----------------------------------------------------------------------------
+    def rope_kv_write(self, qkv, q_out, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d):
+        _need(qkv, torch.float16, "qkv", contiguous=False)
+        assert qkv.dim() == 2 and qkv.stride(1) == 1
+        _need(q_out, torch.float16, "q_out"); _need(k_layer, torch.float16, "k_layer"); _need(v_layer, torch.float16, "v_layer")
+        _need(cos, torch.float16, "cos"); _need(sin, torch.float16, "sin")
+        _need(position_ids, torch.int64, "position_ids"); _need(storage_ids, torch.int64, "storage_ids")
+        m = k_layer.shape[-2]
+        check(self.lib.sq_rope_kv_write_f16(qkv.data_ptr(), qkv.stride(0), q_out.data_ptr(), k_layer.data_ptr(),
+                                            v_layer.data_ptr(), cos.data_ptr(), sin.data_ptr(), position_ids.data_ptr(),
+                                            storage_ids.data_ptr(), qkv.shape[0], n_heads, h_kv, d, m, self._stream()),
+              "sq_rope_kv_write_f16")
+
+    def store_i32(self, dst, values):
+        _need(dst, torch.int32, "dst")
+        v = list(values) + [0] * (4 - len(values))
+        check(self.lib.sq_store_i32(dst.data_ptr(), len(values), int(v[0]), int(v[1]), int(v[2]), int(v[3]),
+                                    self._stream()), "sq_store_i32")
+
+    def tree_attention(self, q, k_layer, v_layer, out, kv_len, scale, dense_mask=None, q_slot0=0, gt=0, n_tree=0,
+                       bitmask=None, ctx=None):
+        """q: [H, q_len, D]; k/v_layer: [H_kv, M, D]; out: [q_len, H*D]."""
+        _need(q, torch.float16, "q"); _need(k_layer, torch.float16, "k_layer"); _need(v_layer, torch.float16, "v_layer")
+        _need(out, torch.float16, "out")
+        n_heads, q_len, d = q.shape
+        h_kv, m, _ = k_layer.shape[-3:]
+        if dense_mask is not None:
+            _need(dense_mask, torch.float16, "dense_mask", contiguous=False)
+            dm = dense_mask.reshape(dense_mask.shape[-2], dense_mask.shape[-1]) if dense_mask.dim() != 2 else dense_mask
+            assert dm.stride(1) == 1 and dm.shape[0] == q_len and dm.shape[1] >= kv_len
+            rc = self.lib.sq_tree_attention_f16(q.data_ptr(), k_layer.data_ptr(), v_layer.data_ptr(), out.data_ptr(),
+                                                q_len, n_heads, h_kv, d, m, kv_len, scale, 0, dm.data_ptr(),
+                                                dm.stride(0), 0, 1, 1, None, 0, None, self._stream())
+        else:
+            words = 0
+            if bitmask is not None:
+                _need(bitmask, torch.int64, "bitmask")
+                words = bitmask.shape[1]
+            rc = self.lib.sq_tree_attention_f16(q.data_ptr(), k_layer.data_ptr(), v_layer.data_ptr(), out.data_ptr(),
+                                                q_len, n_heads, h_kv, d, m, kv_len, scale, 1, None, 0, q_slot0, gt,
+                                                n_tree, _ptr(bitmask), words, _ptr(ctx), self._stream())
+        check(rc, "sq_tree_attention_f16")
+        return out
+
+    # ---- a2 ---------------------------------------------------------------------------------
+    def sample_wor(self, logits, rand, row_ids, k, temperature, out, branch=None, out_off=None):
+        """logits/rand: 2-D fp16 with unit inner stride; row_ids: int32 device tensor or None."""
+        _need(logits, torch.float16, "logits", contiguous=False); _need(rand, torch.float16, "rand", contiguous=False)
+        assert logits.stride(1) == 1 and rand.stride(1) == 1
+        _need(out, torch.int64, "out", contiguous=False)
+        n_rows = row_ids.shape[0] if row_ids is not None else logits.shape[0]
+        if row_ids is not None:
+            _need(row_ids, torch.int32, "row_ids")
+        check(self.lib.sq_sample_wor_f16(logits.data_ptr(), logits.stride(0), rand.data_ptr(), rand.stride(0),
+                                         _ptr(row_ids), n_rows, logits.shape[1], k, float(temperature), out.data_ptr(),
+                                         _ptr(branch), _ptr(out_off), self._stream()), "sq_sample_wor_f16")
+        return out
+
+    def topk(self, logits, row_ids, k, out, branch=None, out_off=None):
+        _need(logits, torch.float16, "logits", contiguous=False)
+        assert logits.stride(1) == 1
+        _need(out, torch.int64, "out", contiguous=False)
+        n_rows = row_ids.shape[0] if row_ids is not None else logits.shape[0]
+        if row_ids is not None:
+            _need(row_ids, torch.int32, "row_ids")
+        check(self.lib.sq_topk_f16(logits.data_ptr(), logits.stride(0), _ptr(row_ids), n_rows, logits.shape[1], k,
+                                   out.data_ptr(), _ptr(branch), _ptr(out_off), self._stream()), "sq_topk_f16")
+        return out
+
+    # ---- a6 / a7 / a8 -----------------------------------------------------------------------
+    def verify_workspace(self, n_tree, device):
+        nbytes = int(self.lib.sq_verify_workspace_bytes(n_tree))
+        return torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)
+
+    def verify_stochastic(self, target_logits, draft_logits, tokens, r, child_off, child_ids, n_tree, gt, temperature,
+                          u24, workspace, result):
+        _need(target_logits, torch.float16, "target_logits"); _need(draft_logits, torch.float16, "draft_logits")
+        _need(tokens, torch.int64, "tokens"); _need(r, torch.float16, "r")
+        _need(child_off, torch.int32, "child_off"); _need(result, torch.int32, "result")
+        vocab = target_logits.shape[-1]
+        assert draft_logits.shape[-1] == vocab and target_logits.shape[0] >= n_tree and draft_logits.shape[0] >= n_tree
+        check(self.lib.sq_verify_stochastic_f16(target_logits.data_ptr(), draft_logits.data_ptr(), tokens.data_ptr(),
+                                                r.data_ptr(), child_off.data_ptr(), _ptr(child_ids), n_tree, vocab, gt,
+                                                float(temperature), int(u24), workspace.data_ptr(), result.data_ptr(),
+                                                self._stream()), "sq_verify_stochastic_f16")
+        return result
+
+    def verify_greedy(self, target_logits, tokens, child_off, child_ids, n_tree, gt, workspace, result):
+        _need(target_logits, torch.float16, "target_logits"); _need(tokens, torch.int64, "tokens")
+        _need(child_off, torch.int32, "child_off"); _need(result, torch.int32, "result")
+        vocab = target_logits.shape[-1]
+        check(self.lib.sq_verify_greedy_f16(target_logits.data_ptr(), tokens.data_ptr(), child_off.data_ptr(),
+                                            _ptr(child_ids), n_tree, vocab, gt, workspace.data_ptr(), result.data_ptr(),
+                                            self._stream()), "sq_verify_greedy_f16")
+        return result
+
+    # ---- row-wise glue ------------------------------------------------------------------------
+    def rmsnorm(self, x, weight, out, eps):
+        _need(x, torch.float16, "x"); _need(weight, torch.float16, "weight"); _need(out, torch.float16, "out")
+        hidden = x.shape[-1]
+        check(self.lib.sq_rmsnorm_f16(x.data_ptr(), weight.data_ptr(), out.data_ptr(), x.numel() // hidden, hidden,
+                                      float(eps), self._stream()), "sq_rmsnorm_f16")
+        return out
+
+    def add_rmsnorm(self, x, residual, sum_out, weight, out, eps):
+        for t, n in ((x, "x"), (residual, "residual"), (sum_out, "sum_out"), (weight, "weight"), (out, "out")):
+            _need(t, torch.float16, n)
+        hidden = x.shape[-1]
+        check(self.lib.sq_add_rmsnorm_f16(x.data_ptr(), residual.data_ptr(), sum_out.data_ptr(), weight.data_ptr(),
+                                          out.data_ptr(), x.numel() // hidden, hidden, float(eps), self._stream()),
+              "sq_add_rmsnorm_f16")
+        return out
+
+    def silu_mul(self, gate_up, out):
+        _need(gate_up, torch.float16, "gate_up"); _need(out, torch.float16, "out")
+        inter = out.shape[-1]
+        check(self.lib.sq_silu_mul_f16(gate_up.data_ptr(), out.data_ptr(), out.numel() // inter, inter, self._stream()),
+              "sq_silu_mul_f16")
+        return out
+
+
+_OPS = None
+
+
+def get_ops():
+    global _OPS
+    if _OPS is None:
+        _OPS = HipOps()
+    return _OPS
+
+
+def set_ops_for_testing(ops):
+    """Install a checker implementation (tests only).  Pass None to restore the HIP path."""
+    global _OPS
+    _OPS = ops
