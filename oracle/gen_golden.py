@@ -267,20 +267,21 @@ def gen_rows_fullvocab(R, out_dir):
 def main():
     R = import_reference()
     out_dir = os.path.join(REPO, "tests", "golden")
-    tiny = (64, 172, 2, 4, 4)       # hidden, inter, layers, heads, kv_heads  (D = 16)
-    tiny_t = (128, 344, 2, 4, 4)    # D = 32
-    gqa_t = (128, 344, 2, 8, 2)     # D = 16, GQA 4:1
+    # head dims are the ones the native attention kernel is built for (64 and 128)
+    tiny = (128, 344, 2, 2, 2)      # hidden, inter, layers, heads, kv_heads  (D = 64)
+    tiny_t = (256, 344, 2, 2, 2)    # D = 128
+    gqa_t = (256, 344, 2, 4, 1)     # D = 64, GQA 4:1
     gm = lambda p: os.path.join(REF, p)
     # config A plumbing: 2-chain growmap, stochastic
     run_case(R, "A_2chain", gm("L40_growmaps/2-chain.pt"), tiny, tiny_t, 1024, 96, 0.6, "stochastic", 16, 6, 17,
              logit_gain=8.0, out_dir=out_dir)
     # config B shape: 128-node Sequoia tree, correlated draft so that paths are non-trivial
-    run_case(R, "B_seq128", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), tiny_t, tiny_t, 1024,
+    run_case(R, "B_seq128", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), tiny, tiny, 1024,
              256, 0.6, "stochastic", 24, 3, 18, logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
     # small demo tree, uncorrelated draft, several steps
     run_case(R, "demo4", gm("demo_tree.pt"), tiny, gqa_t, 1024, 96, 0.6, "stochastic", 12, 8, 19, out_dir=out_dir)
     # config C: greedy 8x8 tree
-    run_case(R, "C_greedy8x8", gm("L40_growmaps/8x8-tree.pt"), tiny_t, tiny_t, 1024, 192, 0.6, "greedy", 20, 4, 20,
+    run_case(R, "C_greedy8x8", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "greedy", 20, 4, 20,
              logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
     # config E shape (64x2) stochastic with GQA target
     run_case(R, "E_64x2", gm("L40_growmaps/64x2-tree.pt"), tiny, gqa_t, 1024, 224, 0.6, "stochastic", 16, 2, 21,

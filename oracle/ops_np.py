@@ -31,8 +31,10 @@ EOS_IDS = (0, 2)                # Tree/SpecTree.py:208
 
 
 def h(x):
-    """fp32 -> fp16, round to nearest even (what every fp16 torch op does to its result)."""
-    return np.asarray(x, dtype=np.float32).astype(np.float16)
+    """fp32 -> fp16, round to nearest even (what every fp16 torch op does to its result);
+    overflow goes to +-inf like torch's cast."""
+    with np.errstate(over="ignore"):
+        return np.asarray(x, dtype=np.float32).astype(np.float16)
 
 
 def f(x):

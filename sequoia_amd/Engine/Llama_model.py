@@ -1,0 +1,321 @@
+"""Llama causal LM over the static slot KV cache, without HF model internals.
+
+Two thin classes keep the reference's names and forward signature
+(Engine/Llama_model.py:136-300): LlamaForCausalLM_FI (draft flavour: attends over all M slots
+through the mask) and LlamaForCausalLM_TG (target flavour: attends over the first kv_len
+slots).  With a masked attention kernel the two are the same computation; they differ only in
+how the key range is derived and validated.
+
+Weights: a HF checkpoint directory (config.json + *.safetensors) or, because this environment
+has no weights, a seeded random init of a named architecture ("random:<arch>[:seed=N]").
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from ..ops import get_ops
+from .Llama_modules import LayerWeights, TreeContext, attention_block, mlp_block, rope_tables
+
+# public HF configs of the model families the reference's scripts name (tests/run_A100.sh etc.)
+KNOWN_ARCHS = {
+    "JackFram/llama-68m": dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=2, num_attention_heads=12,
+                               num_key_value_heads=12),
+    "JackFram/llama-160m": dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                                num_key_value_heads=12),
+    "princeton-nlp/Sheared-LLaMA-1.3B": dict(hidden_size=2048, intermediate_size=5504, num_hidden_layers=24,
+                                             num_attention_heads=16, num_key_value_heads=16),
+    "meta-llama/Llama-2-7b-hf": dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                                     num_attention_heads=32, num_key_value_heads=32),
+    "meta-llama/Llama-2-13b-hf": dict(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40,
+                                      num_attention_heads=40, num_key_value_heads=40),
+    "meta-llama/Llama-2-70b-hf": dict(hidden_size=8192, intermediate_size=28672, num_hidden_layers=80,
+                                      num_attention_heads=64, num_key_value_heads=8),
+}
+
+
+@dataclass
+class LlamaDims:
+    """The subset of LlamaConfig the path needs (attribute names follow HF so KV_Cache and user
+    code written against `model.config` keep working)."""
+    vocab_size: int = 32000
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 32
+    max_position_embeddings: int = 2048
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 10000.0
+    tp_world: int = 1
+    tp_rank: int = 0
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def local_heads(self):
+        return self.num_attention_heads // self.tp_world
+
+    @property
+    def local_kv_heads(self):
+        return max(1, self.num_key_value_heads // self.tp_world)
+
+    @staticmethod
+    def from_any(cfg, **over) -> "LlamaDims":
+        if isinstance(cfg, LlamaDims):
+            d = LlamaDims(**{**cfg.__dict__, **over})
+            return d
+        keys = LlamaDims.__dataclass_fields__.keys()
+        src = cfg if isinstance(cfg, dict) else {k: getattr(cfg, k) for k in keys if hasattr(cfg, k)}
+        vals = {k: src[k] for k in keys if k in src and src[k] is not None}
+        vals.update(over)
+        return LlamaDims(**vals)
+
+
+class KVConfigView:
+    """What KV_Cache reads from a config: per-rank head counts under tensor parallelism."""
+
+    def __init__(self, dims: LlamaDims):
+        self.num_hidden_layers = dims.num_hidden_layers
+        self.num_key_value_heads = dims.local_kv_heads
+        self.num_attention_heads = dims.local_heads
+        self.hidden_size = dims.head_dim * dims.local_heads
+
+
+def _shard_rows(w, rank, world, groups=1):
+    """column-parallel: split the output rows of a [out, in] weight."""
+    if world == 1:
+        return w
+    out = w.shape[0]
+    assert out % world == 0
+    n = out // world
+    return w[rank * n:(rank + 1) * n].contiguous()
+
+
+def _shard_cols(w, rank, world):
+    """row-parallel: split the input columns."""
+    if world == 1:
+        return w
+    n = w.shape[1] // world
+    return w[:, rank * n:(rank + 1) * n].contiguous()
+
+
+class LlamaWeights:
+    """Fused, device-resident weights of one (shard of a) model."""
+
+    def __init__(self, dims: LlamaDims, dtype, device):
+        self.dims, self.dtype, self.device = dims, dtype, device
+        self.embed = None
+        self.layers: list[LayerWeights] = []
+        self.norm = None
+        self.lm_head = None
+
+    # ---- from a HF-style state dict (names as in the reference's LlamaForCausalLM_*) -------------
+    @staticmethod
+    def from_state_dict(sd, dims: LlamaDims, dtype, device) -> "LlamaWeights":
+        w = LlamaWeights(dims, dtype, device)
+        r, ws = dims.tp_rank, dims.tp_world
+        g = lambda k: torch.as_tensor(sd[k]).to(dtype)
+        put = lambda t: t.to(device).contiguous()
+        w.embed = put(g("model.embed_tokens.weight"))
+        for i in range(dims.num_hidden_layers):
+            p = f"model.layers.{i}."
+            q = _shard_rows(g(p + "self_attn.q_proj.weight"), r, ws)
+            kv_world = min(ws, dims.num_key_value_heads)
+            kv_rank = r * kv_world // ws
+            k = _shard_rows(g(p + "self_attn.k_proj.weight"), kv_rank, kv_world)
+            v = _shard_rows(g(p + "self_attn.v_proj.weight"), kv_rank, kv_world)
+            gate = _shard_rows(g(p + "mlp.gate_proj.weight"), r, ws)
+            up = _shard_rows(g(p + "mlp.up_proj.weight"), r, ws)
+            w.layers.append(LayerWeights(
+                ln1=put(g(p + "input_layernorm.weight")),
+                wqkv=put(torch.cat([q, k, v], dim=0)),
+                wo=put(_shard_cols(g(p + "self_attn.o_proj.weight"), r, ws)),
+                ln2=put(g(p + "post_attention_layernorm.weight")),
+                w_gate_up=put(torch.cat([gate, up], dim=0)),
+                w_down=put(_shard_cols(g(p + "mlp.down_proj.weight"), r, ws))))
+        w.norm = put(g("model.norm.weight"))
+        w.lm_head = put(_shard_rows(g("lm_head.weight"), r, ws))
+        return w
+
+    # ---- seeded random init (HF initializer_range = 0.02), generated on the target device --------
+    @staticmethod
+    def random(dims: LlamaDims, dtype, device, seed: int, logit_gain: float = 1.0) -> "LlamaWeights":
+        w = LlamaWeights(dims, dtype, device)
+        gen = torch.Generator(device=device)
+        ws, r = dims.tp_world, dims.tp_rank
+
+        def normal(shape, tag):
+            # one stream per (tensor, rank-independent) so that shards of different ranks are
+            # slices of the same full matrix
+            gen.manual_seed(seed * 1000003 + tag)
+            return torch.empty(shape, dtype=dtype, device=device).normal_(0.0, 0.02, generator=gen)
+
+        h, inter, d = dims.hidden_size, dims.intermediate_size, dims.head_dim
+        hq, hkv = dims.num_attention_heads, dims.num_key_value_heads
+        w.embed = normal((dims.vocab_size, h), 1)
+        ones = lambda: torch.ones(h, dtype=dtype, device=device)
+        for i in range(dims.num_hidden_layers):
+            t = 100 + i * 10
+            if ws == 1:
+                wqkv = normal(((hq + 2 * hkv) * d, h), t)
+                wo = normal((h, hq * d), t + 1)
+                wgu = normal((2 * inter, h), t + 2)
+                wd = normal((h, inter), t + 3)
+            else:
+                full_q = normal((hq * d, h), t); full_k = normal((hkv * d, h), t + 4); full_v = normal((hkv * d, h), t + 5)
+                kv_world = min(ws, hkv); kv_rank = r * kv_world // ws
+                wqkv = torch.cat([_shard_rows(full_q, r, ws), _shard_rows(full_k, kv_rank, kv_world),
+                                  _shard_rows(full_v, kv_rank, kv_world)], dim=0).contiguous()
+                del full_q, full_k, full_v
+                wo = _shard_cols(normal((h, hq * d), t + 1), r, ws)
+                fg = normal((inter, h), t + 2); fu = normal((inter, h), t + 6)
+                wgu = torch.cat([_shard_rows(fg, r, ws), _shard_rows(fu, r, ws)], dim=0).contiguous()
+                del fg, fu
+                wd = _shard_cols(normal((h, inter), t + 3), r, ws)
+            w.layers.append(LayerWeights(ln1=ones(), wqkv=wqkv, wo=wo, ln2=ones(), w_gate_up=wgu, w_down=wd))
+        w.norm = ones()
+        head = normal((dims.vocab_size, h), 2)
+        if logit_gain != 1.0:
+            head.mul_(logit_gain)
+        w.lm_head = _shard_rows(head, r, ws)
+        return w
+
+
+def parse_model_spec(spec):
+    """-> (kind, payload).  kind in {'dir', 'random', 'dims', 'state'}."""
+    if isinstance(spec, (LlamaDims, dict)) and not (isinstance(spec, dict) and "state_dict" in spec):
+        return "dims", spec
+    if isinstance(spec, dict):
+        return "state", spec
+    s = str(spec)
+    if s.startswith("random:"):
+        parts = s.split(":")
+        arch = parts[1]
+        opts = dict(p.split("=", 1) for p in parts[2:] if "=" in p)
+        return "random", (arch, opts)
+    if os.path.isdir(s):
+        return "dir", s
+    raise FileNotFoundError(
+        f"model '{s}' is not a local checkpoint directory; this build has no network access. Use a local HF "
+        f"directory or 'random:<arch>[:seed=N]' with <arch> in {sorted(KNOWN_ARCHS)}")
+
+
+def load_weights(spec, dtype, device, tp_world=1, tp_rank=0, vocab_size=32000):
+    kind, payload = parse_model_spec(spec)
+    if kind == "random":
+        arch, opts = payload
+        if arch not in KNOWN_ARCHS:
+            raise KeyError(f"unknown architecture {arch}")
+        dims = LlamaDims(vocab_size=vocab_size, tp_world=tp_world, tp_rank=tp_rank, **KNOWN_ARCHS[arch])
+        return LlamaWeights.random(dims, dtype, device, int(opts.get("seed", 0)), float(opts.get("gain", 1.0)))
+    if kind == "dims":
+        seed = payload.get("seed", 0) if isinstance(payload, dict) else 0
+        src = {k: v for k, v in payload.items() if k != "seed"} if isinstance(payload, dict) else payload
+        dims = LlamaDims.from_any(src, tp_world=tp_world, tp_rank=tp_rank)
+        return LlamaWeights.random(dims, dtype, device, seed)
+    if kind == "state":
+        dims = LlamaDims.from_any(payload["config"], tp_world=tp_world, tp_rank=tp_rank)
+        return LlamaWeights.from_state_dict(payload["state_dict"], dims, dtype, device)
+    # HF directory
+    with open(os.path.join(payload, "config.json")) as f:
+        cfg = json.load(f)
+    dims = LlamaDims.from_any(cfg, tp_world=tp_world, tp_rank=tp_rank)
+    files = sorted(glob.glob(os.path.join(payload, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {payload}")
+    from safetensors.torch import load_file
+    sd = {}
+    for fpath in files:
+        sd.update(load_file(fpath, device="cpu"))
+    if "lm_head.weight" not in sd:
+        sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+    return LlamaWeights.from_state_dict(sd, dims, dtype, device)
+
+
+class _LlamaForCausalLM:
+    """Shared forward.  `key_range` distinguishes the FI / TG flavours."""
+    key_range = "kv_len"
+
+    def __init__(self, weights: LlamaWeights, reduce_fn=None, gather_logits_fn=None):
+        self.weights = weights
+        self.dims = weights.dims
+        self.config = weights.dims
+        self.vocab_size = weights.dims.vocab_size
+        self.dtype, self.device = weights.dtype, weights.device
+        self.cos, self.sin = rope_tables(self.dims.head_dim, self.dims.max_position_embeddings, self.dims.rope_theta,
+                                         self.device, self.dtype)
+        self.reduce_fn = reduce_fn                  # TP all-reduce hook (None on one GPU)
+        self.gather_logits_fn = gather_logits_fn    # TP vocab all-gather hook
+
+    def eval(self):
+        return self
+
+    @torch.no_grad()
+    def forward(self, input_ids, max_length, storage_ids, attention_mask=None, position_ids=None, kv_cache=None,
+                debug=False, tree: TreeContext | None = None):
+        ops = get_ops()
+        W, dims = self.weights, self.dims
+        if input_ids.dim() != 2 or input_ids.shape[0] != 1:
+            raise ValueError("batch size must be 1 (Engine/Llama_KV.py:8)")
+        q_len = input_ids.shape[1]
+        pos = position_ids.reshape(-1)
+        if pos.shape[0] != q_len or storage_ids.shape[0] != q_len:
+            raise ValueError("position_ids / storage_ids must have one entry per input token")
+        dense = None
+        if tree is None:
+            if attention_mask is None:
+                raise ValueError("attention_mask is required when no TreeContext is given")
+            dense = attention_mask.reshape(attention_mask.shape[-2], attention_mask.shape[-1])
+            kv_len = kv_cache.kv_offset + q_len
+            if self.key_range == "kv_len":
+                # LlamaAttention_TG validates the mask shape (Engine/Llama_modules.py:238-242)
+                if tuple(attention_mask.shape[-2:]) != (q_len, kv_len):
+                    raise ValueError(f"Attention mask should be of size {(1, 1, q_len, kv_len)}, but is "
+                                     f"{tuple(attention_mask.size())}")
+            else:
+                if attention_mask.shape[-1] != max_length or attention_mask.shape[-2] != q_len:
+                    raise ValueError(f"Attention mask should be of size {(1, 1, q_len, max_length)}, but is "
+                                     f"{tuple(attention_mask.size())}")
+            if dense.dtype != self.dtype:
+                dense = dense.to(self.dtype)
+        x = F.embedding(input_ids[0], W.embed)                      # [q, hidden]
+        hbuf = torch.empty_like(x)
+        pending = None                                               # branch output not yet added to x
+        for li, lw in enumerate(W.layers):
+            if pending is None:
+                ops.rmsnorm(x, lw.ln1, hbuf, dims.rms_norm_eps)
+            else:
+                ops.add_rmsnorm(pending, x, x, lw.ln1, hbuf, dims.rms_norm_eps)
+            attn = attention_block(hbuf, lw, li, dims, kv_cache, self.cos, self.sin, pos, storage_ids, dense, tree,
+                                   self.reduce_fn)
+            ops.add_rmsnorm(attn, x, x, lw.ln2, hbuf, dims.rms_norm_eps)
+            pending = mlp_block(hbuf, lw, dims, self.reduce_fn)
+        if pending is None:
+            ops.rmsnorm(x, W.norm, hbuf, dims.rms_norm_eps)
+        else:
+            ops.add_rmsnorm(pending, x, x, W.norm, hbuf, dims.rms_norm_eps)
+        kv_cache.note_written(q_len)
+        logits = F.linear(hbuf, W.lm_head)
+        if self.gather_logits_fn is not None:
+            logits = self.gather_logits_fn(logits)
+        return logits.unsqueeze(0)
+
+    __call__ = forward
+
+
+class LlamaForCausalLM_FI(_LlamaForCausalLM):
+    """Draft flavour (Engine/Llama_model.py:136-216): the mask spans all M slots."""
+    key_range = "max_length"
+
+
+class LlamaForCausalLM_TG(_LlamaForCausalLM):
+    """Target flavour (Engine/Llama_model.py:219-300): keys are the first kv_len slots."""
+    key_range = "kv_len"

@@ -1,0 +1,93 @@
+"""Building blocks of the Llama forward used by both engines.
+
+The reference implements these as nn.Modules on HF internals (Engine/Llama_modules.py); here
+they are plain functions over a fused-weight layer record, with the hot ops in HIP:
+RMSNorm(+residual) -> sq_(add_)rmsnorm_f16, RoPE + KV slot write -> sq_rope_kv_write_f16,
+tree-batched attention -> sq_tree_attention_f16, SwiGLU gate -> sq_silu_mul_f16.  The dense
+projections stay on PyTorch (hipBLASLt) as BASELINE.json's north_star prescribes.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from ..ops import get_ops
+
+
+def rope_tables(head_dim: int, max_pos: int, base: float, device, dtype=torch.float16):
+    """cos/sin caches exactly as LlamaRotaryEmbedding_FI builds them (Engine/Llama_modules.py:
+    17-45): fp32 on the CPU, then cast — so every device sees the same fp16 table."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    t = torch.arange(max_pos, dtype=inv_freq.dtype)
+    freqs = torch.outer(t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype).to(device).contiguous(), emb.sin().to(dtype).to(device).contiguous()
+
+
+@dataclass
+class TreeContext:
+    """Implicit tree-causal mask of one forward: the queries sit at slots
+    [q_slot0, q_slot0+q_len); slots < gt are committed text (causal), slots >= gt are tree
+    nodes gt-1+t whose visibility is the growmap's ancestor bitmask.  `ctx` (optional, device
+    int32[3] = {q_slot0, gt, kv_len}) makes the launch replayable from a hipGraph."""
+    q_slot0: int
+    gt: int
+    n_tree: int
+    bitmask: torch.Tensor          # int64 [n_tree, words] (uint64 bit patterns)
+    kv_len: int
+    ctx: torch.Tensor | None = None
+
+
+@dataclass
+class LayerWeights:
+    ln1: torch.Tensor              # [hidden]
+    wqkv: torch.Tensor             # [(H + 2 H_kv) D, hidden]   packed q | k | v
+    wo: torch.Tensor               # [hidden, H D]
+    ln2: torch.Tensor
+    w_gate_up: torch.Tensor        # [2 I, hidden]              packed gate | up
+    w_down: torch.Tensor           # [hidden, I]
+
+
+def attention_block(h, lw: LayerWeights, layer_idx: int, dims, kv_cache, cos, sin, position_ids, storage_ids,
+                    dense_mask, tree: TreeContext | None, reduce_fn=None):
+    """h: [q, hidden] normalised input.  Returns the o_proj output [q, hidden].
+
+    Replaces LlamaAttention_FI/TG.forward (Engine/Llama_modules.py:87-140, 182-258)."""
+    ops = get_ops()
+    q_len = h.shape[0]
+    n_heads, h_kv, d = dims.local_heads, dims.local_kv_heads, dims.head_dim
+    qkv = F.linear(h, lw.wqkv)                                         # hipBLASLt
+    q_rot = torch.empty((n_heads, q_len, d), dtype=h.dtype, device=h.device)
+    k_layer, v_layer = kv_cache.k_cache[layer_idx, 0], kv_cache.v_cache[layer_idx, 0]
+    ops.rope_kv_write(qkv, q_rot, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d)
+    attn = torch.empty((q_len, n_heads * d), dtype=h.dtype, device=h.device)
+    scale = 1.0 / math.sqrt(d)
+    if tree is not None:
+        ops.tree_attention(q_rot, k_layer, v_layer, attn, tree.kv_len, scale, q_slot0=tree.q_slot0, gt=tree.gt,
+                           n_tree=tree.n_tree, bitmask=tree.bitmask, ctx=tree.ctx)
+    else:
+        if dense_mask is None:
+            raise ValueError("attention needs either a dense additive mask or a TreeContext")
+        kv_len = dense_mask.shape[-1]
+        if kv_len > kv_cache.max_length:
+            raise ValueError(f"Attention mask should cover at most {kv_cache.max_length} key slots, got {kv_len}")
+        ops.tree_attention(q_rot, k_layer, v_layer, attn, kv_len, scale, dense_mask=dense_mask)
+    out = F.linear(attn, lw.wo)
+    if reduce_fn is not None:
+        out = reduce_fn(out)                                           # TP: row-parallel all-reduce
+    return out
+
+
+def mlp_block(h, lw: LayerWeights, dims, reduce_fn=None):
+    """SwiGLU MLP (LlamaMLP_FI, Engine/Llama_modules.py:259-272) with gate|up fused."""
+    ops = get_ops()
+    gu = F.linear(h, lw.w_gate_up)
+    act = torch.empty((h.shape[0], lw.w_down.shape[1]), dtype=h.dtype, device=h.device)
+    ops.silu_mul(gu, act)
+    out = F.linear(act, lw.w_down)
+    if reduce_fn is not None:
+        out = reduce_fn(out)
+    return out

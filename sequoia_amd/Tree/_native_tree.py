@@ -1,0 +1,208 @@
+"""Shared machinery of SpecTree / GreedyTree on the native kernels.
+
+One speculation step = construct_grow_map() (draft expansion, Tree/SpecTree.py:245-259) +
+verify() (target forward, accept walk, bonus token, KV rollback, next-step prep,
+Tree/SpecTree.py:159-281).  State and index algebra follow SURVEY.md §3.7:
+slot == token index == KV slot; tree node t sits at slot gt-1+t; positions of tree nodes are
+depth + gt - 1.
+
+Host <-> device traffic per step: one 256-byte read of the verifier's result record (the step
+API must return the accepted length to the caller); everything else is stream-ordered.
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+
+from ..Engine.Llama_modules import TreeContext
+from ..native import (SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_SLOTS, SQ_RES_TERMINAL, SQ_RESULT_INTS)
+from ..ops import get_ops
+from .Tree import Tree, growmap_on_device
+
+
+def _sync(device):
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+
+
+class NativeTree(Tree):
+    stochastic = True
+
+    def __init__(self, draft_model_engine, target_model_engine, prefix: torch.LongTensor, temperature: float = 0.6,
+                 top_p: float = 0.9, draft_kv_len=0, target_kv_len=0, max_length=256, device: str = "cpu",
+                 max_target_seq=256, vocab_size=32000, grow_map=None, attn_mask=None, sequence=None,
+                 new_tokens_buffer=None, parents_buffer=None, position_ids=None, residual_graph=None,
+                 sampling_callables=None, sample_gather_indices=None, bonus_uniforms=None) -> None:
+        super().__init__(device=device, max_length=max_length)
+        assert self.max_length == draft_model_engine.engine.max_length
+        if self.stochastic and top_p < 1.0:
+            raise NotImplementedError("the native verifier implements top_p = 1.0 (every reference script runs "
+                                      "--P 1.0, tests/run_A100.sh); nucleus filtering is not built yet")
+        self.ops = get_ops()
+        self.max_target_seq = max_target_seq
+        self.draft_model_engine = draft_model_engine
+        self.target_model_engine = target_model_engine
+        self.temperature = temperature
+        self.top_p = top_p
+        self.residual_graph = residual_graph            # accepted for signature compatibility
+        self.grow_map = grow_map
+        self.sampling_callables = sampling_callables
+        self.sample_gather_indices = sample_gather_indices
+        self.vocab_size = vocab_size
+
+        self.gm, self.gdev = growmap_on_device(grow_map, device)
+        self.draft_step = self.gm.draft_step
+        self.Successors = self.gm.successors
+        self.tree_size = self.gm.size
+        self.initialize(attn_mask, sequence, new_tokens_buffer, parents_buffer, position_ids, None)
+        self.set_prefix(prefix=prefix)
+        n, gt = self.tree_size, len(prefix)
+        if gt + n - 1 > self.max_length:
+            raise ValueError(f"prefix ({gt}) + tree ({n}) does not fit max_length {self.max_length} (README.md:47)")
+        self.ground_truth_len = gt
+        if self.stochastic:
+            # same CPU-generator draws, in the same order, as the reference (Tree/SpecTree.py:60,84)
+            self.r = torch.rand(len(position_ids), dtype=self.dtype).to(self.device)
+        self.depth = self.gdev["depth"][1:]
+        self.position_ids[gt: gt + n - 1] = self.depth + (gt - 1)
+        self.storage_ids = torch.arange(self.max_length, device=self.device)
+        self._arange = self.storage_ids
+        self.draft_logits = torch.zeros((max(n, 1), vocab_size), dtype=self.dtype, device=self.device)
+
+        logits = self.draft_model_engine.inference(
+            input_ids=self.tokens[draft_kv_len:self.num_nodes].unsqueeze(0),
+            storage_ids=self.storage_ids[draft_kv_len:self.num_nodes],
+            position_ids=self.position_ids[draft_kv_len:self.num_nodes].unsqueeze(0),
+            attn_mask=None, tree=self._ctx(draft_kv_len, self.num_nodes))
+        self.draft_logits[0] = logits[0, -1]
+        self.draft_kv_len = self.num_nodes
+        self.target_kv_len = target_kv_len
+        if self.stochastic:
+            self.rand = torch.empty((n, vocab_size), dtype=self.dtype).uniform_().to(self.device)
+            if bonus_uniforms is None:
+                bonus_uniforms = torch.randint(0, 1 << 24, (self.max_length + 1,))
+            self.bonus_u24 = [int(x) for x in bonus_uniforms]
+        self.step_idx = 0
+        self.verify_ws = self.ops.verify_workspace(n, self.device)
+        self.result = torch.zeros(SQ_RESULT_INTS, dtype=torch.int32, device=self.device)
+        self.seq_to_use = list(range(self.max_length))
+        self.target_logits = None
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def _ctx(self, q_slot0: int, kv_len: int) -> TreeContext:
+        return TreeContext(q_slot0=q_slot0, gt=self.ground_truth_len, n_tree=self.tree_size,
+                           bitmask=self.gdev["bitmask"], kv_len=kv_len)
+
+    def _sample_level(self, i: int, lv: dict):
+        raise NotImplementedError
+
+    def _verify_native(self, gt: int):
+        raise NotImplementedError
+
+    # ---- draft expansion --------------------------------------------------------------------------
+    @torch.inference_mode()
+    def collective_grow_static(self, idx_list, n_branch_list, benchmark=False, grow_step=None):
+        lv = self.gdev["levels"][grow_step]
+        total_branch = lv["total"]
+        x1 = x2 = 0.0
+        if benchmark:
+            _sync(self.device); t1 = time.time()
+        self._sample_level(grow_step, lv)
+        if benchmark:
+            _sync(self.device); t2 = time.time(); x1 += t2 - t1
+        start_pos = self.num_nodes
+        self.num_nodes = self.num_nodes + total_branch
+        end_pos = self.num_nodes
+        logits = self.draft_model_engine.graph_inference(
+            input_ids=self.tokens[self.draft_kv_len:end_pos].unsqueeze(0),
+            position_ids=self.position_ids[start_pos:end_pos].unsqueeze(0),
+            attn_mask=None, storage_ids=self.storage_ids[self.draft_kv_len:end_pos],
+            tree=self._ctx(self.draft_kv_len, end_pos))
+        self.draft_kv_len = end_pos
+        first = start_pos - self.ground_truth_len + 1
+        self.draft_logits[first:first + total_branch] = logits[0][-total_branch:]
+        if benchmark:
+            _sync(self.device); t3 = time.time(); x2 += t3 - t2
+            return n_branch_list, x1, x2
+        return n_branch_list
+
+    def construct_grow_map(self, benchmark=False):
+        sample_time = compute_time = 0.0
+        for i in range(self.draft_step - 1):
+            out = self.collective_grow_static(self.gm.roots[i], self.gm.branches[i], benchmark=benchmark, grow_step=i)
+            if benchmark:
+                sample_time += out[1]; compute_time += out[2]
+        return (sample_time, compute_time) if benchmark else None
+
+    # ---- verification -----------------------------------------------------------------------------
+    @torch.inference_mode()
+    def verify(self, benchmark=False):
+        gt, n = self.ground_truth_len, self.tree_size
+        new_node_num = self.num_nodes - gt + 1
+        start_pos = self.target_kv_len
+        end_pos = self.num_nodes
+        if benchmark:
+            _sync(self.device); t1 = time.time()
+        out = self.target_model_engine.inference(
+            input_ids=self.tokens[start_pos:end_pos].unsqueeze(0),
+            position_ids=self.position_ids[start_pos:end_pos].unsqueeze(0), attn_mask=None,
+            storage_ids=self.storage_ids[start_pos:end_pos], tree=self._ctx(start_pos, end_pos))
+        if benchmark:
+            _sync(self.device); t2 = time.time()
+        self.target_logits = out[0][gt - 1 - start_pos:] if start_pos == 0 else out[0][-new_node_num:]
+        assert len(self.target_logits) == new_node_num == n
+
+        self._verify_native(gt)
+        res = self.result.cpu()                      # the step's only device->host synchronisation
+        accept_length = int(res[SQ_RES_ACCEPT_LEN])
+        n_acc = int(res[SQ_RES_N_TREE])
+        terminal = bool(res[SQ_RES_TERMINAL])
+        self.last_result = res
+        accept_list = self.seq_to_use[:gt] + [int(s) for s in res[SQ_RES_SLOTS:SQ_RES_SLOTS + min(n_acc, SQ_RESULT_INTS - SQ_RES_SLOTS)]]
+        if benchmark:
+            _sync(self.device); t3 = time.time()
+        self.step_idx += 1
+
+        if self._compact_when_terminal or not terminal:
+            slots, count = self.result[SQ_RES_SLOTS:], self.result[SQ_RES_N_TREE:SQ_RES_N_TREE + 1]
+            max_count = min(n_acc, SQ_RESULT_INTS - SQ_RES_SLOTS)
+            if n_acc > SQ_RESULT_INTS - SQ_RES_SLOTS:        # chains deeper than the record: path lives in the workspace
+                raise NotImplementedError("accepted paths longer than 56 nodes")
+            self.draft_model_engine.engine.kv_cache.compact_from_device(slots, count, max_count, gt, accept_length)
+            self.target_model_engine.engine.kv_cache.compact_from_device(slots, count, max_count, gt, accept_length)
+
+        if not terminal:
+            if benchmark:
+                _sync(self.device); t4 = time.time()
+            self.prepare_for_next_iter(accept_list, self.tokens[:accept_length + 1])
+            if benchmark:
+                return self.tokens[:accept_length + 1], accept_length, accept_length, t2 - t1, t3 - t2, t4 - t3, terminal
+            return self.tokens[:accept_length + 1], accept_length, accept_length, terminal
+        if benchmark:
+            _sync(self.device); t4 = time.time()
+            return self.tokens[:accept_length], accept_length, accept_length, t2 - t1, t3 - t2, t4 - t3, terminal
+        return self.tokens[:accept_length], accept_length, accept_length, terminal
+
+    def prepare_for_next_iter(self, accept_list, valid_tokens: torch.LongTensor):
+        a = len(accept_list)
+        if a + 1 > self.max_target_seq:
+            return
+        new_gt = len(valid_tokens)          # a + 1
+        n = self.tree_size
+        if new_gt + n - 1 > self.max_length:
+            raise ValueError(f"{new_gt} committed tokens + tree ({n}) exceed max_length {self.max_length}")
+        # accepted node j of the path sat at depth j+1, i.e. position gt+j == its new index, so the
+        # compacted prefix is simply 0..a (Tree/SpecTree.py:264-266 evaluates to the same values)
+        self.position_ids[:new_gt] = self._arange[:new_gt]
+        torch.add(self.depth, new_gt - 1, out=self.position_ids[new_gt:new_gt + n - 1])
+        self.ground_truth_len = new_gt
+        self.num_nodes = new_gt
+        logits = self.draft_model_engine.graph_inference(
+            input_ids=self.tokens[a:new_gt].unsqueeze(0), storage_ids=self.storage_ids[a:new_gt],
+            position_ids=self.position_ids[a:new_gt].unsqueeze(0), attn_mask=None, tree=self._ctx(a, new_gt))
+        self.draft_logits[0] = logits[0, -1]
+        self.draft_kv_len = new_gt
+        self.target_kv_len = a
+
+    _compact_when_terminal = True

@@ -1,0 +1,112 @@
+"""Shared test helpers: build engines from a golden trace's recorded weights and replay the
+speculation loop."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from conftest import load_trace
+
+
+def state_dict_of(z, prefix):
+    sd = {}
+    for k in z.files:
+        if k.startswith(prefix + "/"):
+            sd[k[len(prefix) + 1:]] = torch.from_numpy(z[k])
+    return sd
+
+
+def dims_dict(dims5, vocab):
+    hidden, inter, layers, heads, kv = dims5
+    return dict(vocab_size=vocab, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                num_attention_heads=heads, num_key_value_heads=kv, max_position_embeddings=2048)
+
+
+def build_engines(z, meta, device):
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
+    M = meta["M"]
+    dspec = dict(state_dict=state_dict_of(z, "draft"), config=dims_dict(meta["draft_dims"], meta["vocab"]))
+    tspec = dict(state_dict=state_dict_of(z, "target"), config=dims_dict(meta["target_dims"], meta["vocab"]))
+    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
+    target = GraphInferenceEngineTG(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
+    return draft, target
+
+
+def make_tree(z, meta, draft, target, device, cls=None):
+    from sequoia_amd.growmap import GrowMap
+    from sequoia_amd.Tree.GreedyTree import GreedyTree
+    from sequoia_amd.Tree.SpecTree import SpecTree
+    M = meta["M"]
+    g = GrowMap.from_successors(meta["successors"]).to_reference_dict()
+    cls = cls or (SpecTree if meta["mode"] == "stochastic" else GreedyTree)
+    torch.manual_seed(meta["seed"] + 7)          # same noise seed as oracle/gen_golden.py
+    tree = cls(prefix=torch.from_numpy(z["prompt"]), device=device, temperature=meta["T"], top_p=1.0, draft_kv_len=0,
+               target_kv_len=0, draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
+               grow_map=g, attn_mask=torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16, device=device),
+               sequence=None, new_tokens_buffer=None, parents_buffer=None,
+               position_ids=torch.zeros(M, device=device).long(), residual_graph=None, sampling_callables=None,
+               sample_gather_indices=None, vocab_size=meta["vocab"],
+               bonus_uniforms=[int(x) for x in z["bonus_u24"]])
+    return tree
+
+
+def replay_trace(name, device, max_steps=None):
+    """Run the native loop on a trace's weights / prompt / noise.  Returns per-step records
+    (valid tokens, accept length) next to the reference's."""
+    z, meta = load_trace(name)
+    draft, target = build_engines(z, meta, device)
+    tree = make_tree(z, meta, draft, target, device)
+    n_steps = int(z["n_steps"]) if max_steps is None else min(max_steps, int(z["n_steps"]))
+    out = []
+    for s in range(n_steps):
+        tree.construct_grow_map()
+        tokens_pre = tree.tokens.cpu().numpy().copy()
+        draft_logits = tree.draft_logits.float().cpu().numpy().copy()
+        valid, a, _, terminal = tree.verify()
+        out.append(dict(valid=valid.cpu().numpy().copy(), accept_len=int(a), terminal=bool(terminal),
+                        tokens_pre=tokens_pre, draft_logits=draft_logits,
+                        target_logits=tree.target_logits.float().cpu().numpy().copy(),
+                        ref_valid=z[f"step{s}/valid_tokens"],
+                        ref_tokens_pre=z[f"step{s}/tokens_pre"], ref_accept_len=int(z[f"step{s}/accept_len"]),
+                        gt=int(z[f"step{s}/gt"])))
+        if terminal:
+            break
+    return out, tree, draft, target, z, meta
+
+
+def check_replay(steps, z, meta, logit_tol=4e-2):
+    """Compare a replay with the reference trace, step by step.
+
+    Requirements (the parity statement of DESIGN.md §3):
+      * committed tokens entering every compared step are identical;
+      * for every tree node whose token path equals the reference's, the draft and target
+        logits agree within `logit_tol` (a few fp16 ulps at |logit| ~ 8: GEMM / attention
+        accumulation order is the only difference);
+      * the accepted tokens of the step are identical -- unless the run is stochastic and the
+        step is the first one where a decision margin fell inside that tolerance, in which case
+        the comparison stops there (returned as `diverged_at`).
+    Returns (n_matched_steps, diverged_at or None)."""
+    import numpy as np
+    succ = meta["successors"]
+    n = len(succ)
+    parent = {c: p for p, ch in enumerate(succ) for c in ch}
+    for s, rec in enumerate(steps):
+        gt = rec["gt"]
+        assert np.array_equal(rec["tokens_pre"][:gt], rec["ref_tokens_pre"][:gt]), f"step {s}: committed tokens differ"
+        same_tok = rec["tokens_pre"][gt - 1:gt + n - 1] == rec["ref_tokens_pre"][gt - 1:gt + n - 1]
+        ok = [0]
+        okset = {0}
+        for t in range(1, n):
+            if parent[t] in okset and same_tok[t]:
+                ok.append(t); okset.add(t)
+        ref_d = z[f"step{s}/draft_logits_pre"].astype(np.float32)
+        ref_t = z[f"step{s}/target_logits"].astype(np.float32)
+        internal = [t for t in ok if len(succ[t])]
+        dd = np.abs(rec["draft_logits"][internal] - ref_d[internal]).max() if internal else 0.0
+        dt = np.abs(rec["target_logits"][ok] - ref_t[ok]).max()
+        assert dd <= logit_tol and dt <= logit_tol, f"step {s}: logits off by {dd:.4f} / {dt:.4f}"
+        if rec["accept_len"] == rec["ref_accept_len"] and np.array_equal(rec["valid"], rec["ref_valid"]):
+            continue
+        assert meta["mode"] == "stochastic", f"greedy step {s} must be bit-exact"
+        return s, s
+    return len(steps), None

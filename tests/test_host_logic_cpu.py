@@ -1,0 +1,84 @@
+"""Host logic on CPU: the framework's engines + trees (sequoia_amd.Engine / sequoia_amd.Tree)
+driven with the numpy-oracle ops adapter must reproduce the *reference's own* speculation
+traces (tests/golden/trace_*.npz: same weights, prompt, noise, bonus uniforms).
+
+This pins the index algebra, KV protocol, growmap handling and step bookkeeping of the host
+code against the reference; the HIP kernels themselves are checked on the GPU
+(tests/test_hip_kernels.py, tests/test_e2e_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TRACE_NAMES
+from helpers import check_replay, replay_trace
+
+
+@pytest.fixture()
+def oracle_ops():
+    from oracle.ops_adapter import OracleOps
+    from sequoia_amd import ops
+    ops.set_ops_for_testing(OracleOps())
+    yield
+    ops.set_ops_for_testing(None)
+
+
+@pytest.mark.parametrize("name", TRACE_NAMES)
+def test_native_loop_reproduces_reference_trace(oracle_ops, name):
+    steps, tree, draft, target, z, meta = replay_trace(name, "cpu")
+    assert len(steps) == int(z["n_steps"])
+    matched, diverged = check_replay(steps, z, meta)
+    # on CPU every committed trace reproduces the reference's accepted tokens in every step
+    assert diverged is None and matched == len(steps), f"{name}: diverged at step {diverged}"
+    # KV protocol: offsets after the last step equal the reference's
+    last = len(steps) - 1
+    assert draft.engine.kv_cache.kv_offset == int(z[f"step{last}/kv_draft"][2])
+    assert target.engine.kv_cache.kv_offset == int(z[f"step{last}/kv_target"][2])
+    assert np.array_equal(tree.position_ids.numpy(), z[f"step{last}/position_ids_post"])
+
+
+def test_kv_cache_bytes_match_reference_with_full_zero_policy(oracle_ops, monkeypatch):
+    """With the reference's zero policy the target cache is identical up to attention rounding;
+    the *structure* (which slots are live, which are zero) is identical exactly."""
+    from sequoia_amd.Engine.Llama_KV import KV_Cache
+    monkeypatch.setattr(KV_Cache, "ZERO_POLICY", "full")
+    steps, tree, draft, target, z, meta = replay_trace("B_seq128", "cpu")
+    ref_k = z["final/target_k"]
+    got_k = target.engine.kv_cache.k_cache.numpy()
+    assert got_k.shape == ref_k.shape
+    assert np.array_equal(np.abs(got_k).sum(-1) == 0, np.abs(ref_k).sum(-1) == 0)
+    live = np.abs(ref_k).sum(-1) != 0
+    # layer 0 keys depend only on embeddings + RoPE (no attention upstream): bit-exact
+    assert np.array_equal(got_k[0][live[0]], ref_k[0][live[0]])
+    assert np.abs(got_k.astype(np.float32) - ref_k.astype(np.float32)).max() < 5e-2
+
+
+def test_foreign_sampling_callable_is_honoured(oracle_ops):
+    """A caller-supplied sampler (the reference's injection seam, tests/testbed.py:269-285) is used
+    verbatim when it is not one of ours."""
+    from conftest import load_trace
+    from helpers import build_engines, make_tree
+    z, meta = load_trace("demo4")
+    draft, target = build_engines(z, meta, "cpu")
+    tree = make_tree(z, meta, draft, target, "cpu")
+    calls = []
+
+    def fake(logits, rand):
+        calls.append(logits.shape)
+        return torch.full((logits.shape[0],), 7, dtype=torch.long)
+    tree.sampling_callables = {i: fake for i in range(tree.draft_step - 1)}
+    tree.sample_gather_indices = {i: torch.zeros(1, dtype=torch.long) for i in range(tree.draft_step - 1)}
+    gt = tree.ground_truth_len
+    tree.construct_grow_map()
+    assert len(calls) == tree.draft_step - 1
+    assert (tree.tokens[gt:gt + tree.tree_size - 1] == 7).all()
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: the HIP ops object rejects host tensors loudly."""
+    from sequoia_amd import native, ops
+    ops.set_ops_for_testing(None)
+    o = ops.get_ops()
+    assert o.name == "hip"
+    x = torch.zeros(4, 8, dtype=torch.float16)
+    with pytest.raises(native.SequoiaNativeError):
+        o.rmsnorm(x, torch.ones(8, dtype=torch.float16), torch.empty_like(x), 1e-6)
