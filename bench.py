@@ -1,0 +1,319 @@
+#!/usr/bin/env python
+"""bench.py — accepted tokens/sec of the Sequoia speculation loop on MI355X.
+
+Workload (BASELINE.json configs[1]): JackFram/llama-68m draft -> Llama-2-7b target
+architectures (random-init weights, no checkpoints offline), growmap
+A100-CNN-68m-7b-stochastic (128-node tree), T = 0.6, top-p = 1.0, M = 384, prompts = first 128
+tokens of the reference's c4_small rows, generation to 256 tokens — the loop of
+tests/testbed.py:45-95 (`simulation_fast`).  A "step" is one speculation step:
+construct_grow_map() + verify().
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 = independent replicas (one process per GPU, prompts sharded rank::world, no data-path
+collective: the loop is a batch-1 latency loop).
+Prints one JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+MODELS = {
+    "B": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="A100-CNN-68m-7b-stochastic",
+              mode="stochastic", M=384),
+    "C": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="8x8-tree", mode="greedy", M=384),
+    "D": dict(draft="princeton-nlp/Sheared-LLaMA-1.3B", target="meta-llama/Llama-2-13b-hf",
+              growmap="A100-CNN-160m-13b-stochastic", mode="stochastic", M=384),
+}
+
+
+def load_prompts():
+    with open(os.path.join(REPO, "sequoia_amd", "growmaps", "c4_small_prompts.json")) as f:
+        return json.load(f)["prompts"]
+
+
+def build(cfg, device, pair, seed_d=1, seed_t=2):
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
+    from sequoia_amd.growmap import GrowMap
+    M = cfg["M"]
+    if pair == "calibrated":
+        from sequoia_amd.synthetic import calibrated_pair_specs
+        dspec, tspec = calibrated_pair_specs(cfg["draft"], cfg["target"], device)
+    else:
+        dspec, tspec = f"random:{cfg['draft']}:seed={seed_d}", f"random:{cfg['target']}:seed={seed_t}"
+    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
+    target = GraphInferenceEngineTG(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
+    gm = GrowMap.load(cfg["growmap"])
+    return draft, target, gm
+
+
+class Loop:
+    """simulation_fast (tests/testbed.py:45-95) as a resumable step iterator."""
+
+    def __init__(self, cfg, draft, target, gm, device, prompts, use_graphs=True, T=0.6):
+        from sequoia_amd.Tree.GreedyTree import GreedyTree
+        from sequoia_amd.Tree.SpecTree import SpecTree
+        from sequoia_amd.Tree.Tree import growmap_on_device
+        self.cfg, self.draft, self.target, self.device, self.prompts, self.T = cfg, draft, target, device, prompts, T
+        self.grow_map = gm.to_reference_dict()
+        self.cls = SpecTree if cfg["mode"] == "stochastic" else GreedyTree
+        M = cfg["M"]
+        self.attn_mask = torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16, device=device)
+        self.position_ids = torch.zeros(M, dtype=torch.long, device=device)
+        g, gdev = growmap_on_device(self.grow_map, device)
+        if use_graphs:
+            lens = sorted({lv.total for lv in g.levels} | {1})
+            draft.initialize_cuda_graph(lens, tree_bitmask=gdev["bitmask"], n_tree=g.size)
+            target.initialize_cuda_graph([g.size], tree_bitmask=gdev["bitmask"], n_tree=g.size)
+        self.pi = 0
+        self.tree = None
+        self.cur_len = 0
+
+    def _new_prompt(self):
+        self.draft.clear_kv(); self.target.clear_kv()
+        p = torch.tensor(self.prompts[self.pi % len(self.prompts)][:128], dtype=torch.long)
+        self.pi += 1
+        M = self.cfg["M"]
+        self.tree = self.cls(prefix=p, device=self.device, temperature=self.T, top_p=1.0, draft_kv_len=0,
+                             target_kv_len=0, draft_model_engine=self.draft, target_model_engine=self.target,
+                             max_length=M, max_target_seq=M, grow_map=self.grow_map, attn_mask=self.attn_mask,
+                             sequence=None, new_tokens_buffer=None, parents_buffer=None,
+                             position_ids=self.position_ids, residual_graph=None, sampling_callables=None,
+                             sample_gather_indices=None)
+        self.cur_len = len(p)
+
+    def run_steps(self, k_steps, timed=True):
+        """Run exactly k_steps speculation steps; per-prompt setup (tree constructor + draft
+        prefill) is outside the timed brackets like the reference (tests/testbed.py:67-79).
+        Returns (seconds, new_tokens, steps)."""
+        total_t, new_tok, done = 0.0, 0, 0
+        while done < k_steps:
+            if self.tree is None:
+                self._new_prompt()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            while done < k_steps and self.tree is not None:
+                self.tree.construct_grow_map()
+                valid, _, _, terminate = self.tree.verify()
+                new_tok += valid.shape[0] - self.cur_len
+                self.cur_len = valid.shape[0]
+                done += 1
+                if terminate or self.cur_len >= 256 or int(valid[-1]) in (0, 2):
+                    self.tree = None
+            torch.cuda.synchronize()
+            total_t += time.perf_counter() - t1
+        return total_t, new_tok, done
+
+
+def kernel_rooflines(cfg, loop, device):
+    """Per-kernel average duration at the workload's shapes, HIP events on the launch stream
+    (torch's current stream is the one the C ABI launches on), and algorithmic bytes
+    (SURVEY.md §8d formulas)."""
+    from sequoia_amd.ops import get_ops
+    ops = get_ops()
+    tgt, drf = loop.target.engine, loop.draft.engine
+    gm, gdev = loop.tree.gm if loop.tree else None, None
+    from sequoia_amd.Tree.Tree import growmap_on_device
+    g, gdev = growmap_on_device(loop.grow_map, device)
+    n, V, M = g.size, 32000, cfg["M"]
+    dims = tgt.model.dims
+    H, Hkv, D, L = dims.num_attention_heads, dims.num_key_value_heads, dims.head_dim, dims.num_hidden_layers
+    gt = 160
+    kv_len = gt - 1 + n
+    res = {}
+
+    def timeit(fn, reps=200):
+        for _ in range(10):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    # target tree attention, one layer (launched L times per verify)
+    q = torch.randn(H, n, D, device=device).half()
+    out = torch.empty(n, H * D, dtype=torch.float16, device=device)
+    kc, vc = tgt.kv_cache.k_cache, tgt.kv_cache.v_cache
+    kc.normal_(); vc.normal_()
+    layer = [0]
+
+    def attn():
+        l = layer[0] % L
+        layer[0] += 1
+        ops.tree_attention(q, kc[l, 0], vc[l, 0], out, kv_len, D ** -0.5, q_slot0=gt - 1, gt=gt, n_tree=n,
+                           bitmask=gdev["bitmask"])
+    t = timeit(attn, 320)
+    byts = 2 * Hkv * kv_len * D * 2 + 2 * H * n * D * 2
+    res["tree_attention_target"] = dict(seconds=t, bytes=byts, launches_per_step=L,
+                                        flops=4 * H * n * kv_len * D)
+    # verifier (nodes + walk)
+    n_internal = sum(1 for s in g.successors if s)
+    if cfg["mode"] == "stochastic":
+        tl = (torch.randn(n, V, device=device) * 3).half()
+        dl = (tl.float() + torch.randn(n, V, device=device) * 2).half()
+        toks = torch.randint(3, V, (M,), device=device)
+        r = torch.rand(M, device=device).half()
+        ws = ops.verify_workspace(n, device)
+        rr = torch.zeros(64, dtype=torch.int32, device=device)
+        dl2 = dl.clone()
+
+        def ver():
+            ops.verify_stochastic(tl, dl2, toks, r, gdev["child_off"], gdev["child_ids"], n, gt, 0.6, 12345, ws, rr)
+        t = timeit(ver, 50)
+        res["verify_stochastic"] = dict(seconds=t, bytes=(n + n_internal) * V * 2, launches_per_step=1)
+        # sampler, all levels of one step
+        rand = torch.rand(n, V, device=device).half()
+        tokbuf = torch.zeros(M, dtype=torch.long, device=device)
+
+        def samp():
+            for lv in gdev["levels"]:
+                ops.sample_wor(dl, rand, lv["row_ids"], lv["k"], 0.6, tokbuf, branch=lv["branch"], out_off=lv["out_off"])
+        t = timeit(samp, 50)
+        rows = sum(lv["n_rows"] for lv in gdev["levels"])
+        res["sample_wor_all_levels"] = dict(seconds=t, bytes=rows * V * 4 + sum(lv["total"] for lv in gdev["levels"]) * 8,
+                                            launches_per_step=len(gdev["levels"]))
+    # KV compaction of 4 accepted nodes on the target cache
+    slots = torch.tensor([gt + 1, gt + 20, gt + 50, gt + 90], dtype=torch.int32, device=device)
+
+    def comp():
+        ops.kv_compact(kc, vc, slots, None, 4, gt, 0)
+    t = timeit(comp, 200)
+    res["kv_compact_target"] = dict(seconds=t, bytes=4 * 2 * L * Hkv * D * 2 * 2, launches_per_step=1)
+    kc.zero_(); vc.zero_()
+    return res
+
+
+def cpu_baseline(cfg, n_steps=2):
+    """The CPU path timed on this box's host cores: the same host loop with the numpy oracle ops
+    (oracle/ops_adapter.py) and PyTorch CPU GEMMs, fp16 like the reference, on a bounded sample
+    (n_steps speculation steps of the first prompt; the first includes the 255-token prefill)."""
+    from oracle.ops_adapter import OracleOps
+    from sequoia_amd import ops as ops_mod
+    prev = ops_mod._OPS
+    ops_mod.set_ops_for_testing(OracleOps())
+    try:
+        t0 = time.perf_counter()
+        draft, target, gm = build(cfg, "cpu", "random")
+        build_s = time.perf_counter() - t0
+        loop = Loop.__new__(Loop)
+        from sequoia_amd.Tree.GreedyTree import GreedyTree
+        from sequoia_amd.Tree.SpecTree import SpecTree
+        M = cfg["M"]
+        cls = SpecTree if cfg["mode"] == "stochastic" else GreedyTree
+        p = torch.tensor(load_prompts()[0][:128], dtype=torch.long)
+        tree = cls(prefix=p, device="cpu", temperature=0.6, top_p=1.0, draft_kv_len=0, target_kv_len=0,
+                   draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
+                   grow_map=gm.to_reference_dict(), attn_mask=None, sequence=None, new_tokens_buffer=None,
+                   parents_buffer=None, position_ids=torch.zeros(M, dtype=torch.long), residual_graph=None,
+                   sampling_callables=None, sample_gather_indices=None)
+        t1 = time.perf_counter()
+        cur, new_tok, done = len(p), 0, 0
+        for _ in range(n_steps):
+            tree.construct_grow_map()
+            valid, _, _, term = tree.verify()
+            new_tok += valid.shape[0] - cur
+            cur = valid.shape[0]
+            done += 1
+            if term:
+                break
+        dt = time.perf_counter() - t1
+        return dict(value=new_tok / dt, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+                    sample=f"{done} speculation steps of prompt 0 (first step includes the 255-token target prefill), "
+                           f"config {cfg['draft']} -> {cfg['target']}, numpy oracle ops + torch CPU fp16 GEMMs, "
+                           f"{dt:.1f} s timed (+{build_s:.0f} s weight init)",
+                    steps_per_s=done / dt)
+    finally:
+        ops_mod.set_ops_for_testing(prev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="B", choices=sorted(MODELS))
+    ap.add_argument("--pair", default="calibrated", choices=["calibrated", "random"])
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    device = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    torch.manual_seed(17 + rank)
+
+    cfg = MODELS[args.config]
+    draft, target, gm = build(cfg, device, args.pair)
+    prompts = load_prompts()[rank::world] if world > 1 else load_prompts()
+    loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs)
+
+    loop.run_steps(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    secs, new_tok, steps = loop.run_steps(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([secs], device=device); dist.all_reduce(t, op=dist.ReduceOp.MAX); secs = float(t)
+        c = torch.tensor([float(new_tok), float(steps)], device=device); dist.all_reduce(c)
+        new_tok, steps_all = float(c[0]), float(c[1])
+    else:
+        steps_all = steps
+
+    if rank == 0:
+        kr = kernel_rooflines(cfg, loop, device)
+        per_step = {k: v["seconds"] * (v["launches_per_step"] if k == "tree_attention_target" else 1) for k, v in kr.items()}
+        dom = max(per_step, key=per_step.get)
+        d = kr[dom]
+        peak_hbm = 8000.0
+        roof = dict(bound="hbm", kernel=dom, achieved=d["bytes"] / d["seconds"] / 1e9, peak=peak_hbm, unit="GB/s",
+                    frac=d["bytes"] / d["seconds"] / 1e9 / peak_hbm, traffic=None,
+                    avg_launch_us=d["seconds"] * 1e6, algorithmic_bytes_per_launch=d["bytes"],
+                    time_per_step_us=per_step[dom] * 1e6)
+        kernels = {k: dict(avg_us=v["seconds"] * 1e6, gbps=v["bytes"] / v["seconds"] / 1e9,
+                           per_step_us=per_step[k] * 1e6) for k, v in kr.items()}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cpu = cpu_baseline(cfg, args.cpu_steps)
+            except Exception as e:  # the baseline is a report, never the measured path
+                cpu = dict(value=None, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+                           sample=f"failed: {type(e).__name__}: {e}")
+        line = dict(metric="accepted tokens/sec", value=new_tok / secs, unit="tokens/s", n_gpus=world,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=secs / args.steps * 1e3,
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
+                    config=dict(workload=f"config {args.config}: {cfg['draft']} -> {cfg['target']} architectures "
+                                         f"({args.pair} random-init weights), growmap {cfg['growmap']} "
+                                         f"({gm.size}-node tree), T=0.6, top_p=1.0, M={cfg['M']}, 128-token c4_small "
+                                         f"prompts, generate to 256",
+                                parallelism="replicas" if world > 1 else "single", graphs=not args.no_graphs),
+                    mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs,
+                    roofline=roof, kernels=kernels, cpu_baseline=cpu)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -209,6 +209,10 @@ def parse_model_spec(spec):
 
 
 def load_weights(spec, dtype, device, tp_world=1, tp_rank=0, vocab_size=32000):
+    if isinstance(spec, dict) and isinstance(spec.get("weights"), LlamaWeights):
+        return spec["weights"]                    # prebuilt (sequoia_amd.synthetic)
+    if isinstance(spec, LlamaWeights):
+        return spec
     kind, payload = parse_model_spec(spec)
     if kind == "random":
         arch, opts = payload
