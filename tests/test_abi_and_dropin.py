@@ -1,0 +1,91 @@
+"""CPU checks of the C-ABI boundary and the drop-in aliases (no GPU, no compute launches)."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sequoia_amd import native
+    lib = native.load()
+    header = open(os.path.join(REPO, "include", "sequoia_hip.h")).read()
+    declared = set(re.findall(r"\b(sq_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/sequoia_hip.h but not exported"
+    assert declared == set(native.PROTOTYPES), declared ^ set(native.PROTOTYPES)
+    assert lib.sq_version() >= 100
+
+
+def test_host_helper_bitmask_matches_growmap_masks():
+    """sq_tree_bitmask_from_successors (host code of the library) on every bundled growmap ==
+    the mask the reference stores in its .pt files (sha recorded by oracle/export_fixtures.py)."""
+    import hashlib
+    import json
+    from sequoia_amd import native
+    from sequoia_amd.growmap import BUILTIN_DIR, GrowMap
+    lib = native.load()
+    for fn in sorted(os.listdir(BUILTIN_DIR)):
+        if not fn.endswith(".json") or "prompts" in fn:
+            continue
+        rec = json.load(open(os.path.join(BUILTIN_DIR, fn)))
+        g = GrowMap.from_successors(rec["Successors"])
+        out = np.zeros_like(g.bitmask)
+        rc = lib.sq_tree_bitmask_from_successors(g.child_off.ctypes.data,
+                                                 g.child_ids.ctypes.data if g.size > 1 else None, g.size,
+                                                 out.ctypes.data, out.shape[1])
+        assert rc == 0 and np.array_equal(out, g.bitmask), fn
+        chk = rec["check"]
+        assert g.roots == chk["roots"] and g.branches == chk["branches"] and g.depth.tolist() == chk["depth"], fn
+        assert hashlib.sha256(g.dense_mask().tobytes()).hexdigest() == chk["mask_sha"], fn
+        ref = g.to_reference_dict()
+        assert ref["size"] == rec["size"] and ref["Successors"] == rec["Successors"]
+
+
+def test_argument_validation_returns_error_codes():
+    from sequoia_amd import native
+    lib = native.load()
+    assert lib.sq_tree_bitmask_from_successors(None, None, 4, None, 1) == native.SQ_EINVAL
+    assert lib.sq_kv_compact_f16(None, None, 1, 1, 8, 64, None, None, 0, 0, 0, None) == native.SQ_EINVAL
+    assert lib.sq_sample_wor_f16(None, 0, None, 0, None, 1, 32000, 4, 0.6, None, None, None, None) == native.SQ_EINVAL
+    assert lib.sq_verify_workspace_bytes(128) > 0 and lib.sq_verify_workspace_bytes(0) == 0
+    with pytest.raises(native.SequoiaNativeError):
+        native.check(native.SQ_EUNSUPPORTED, "x")
+
+
+def test_dropin_aliases_resolve_to_this_package():
+    import sequoia_amd.dropin as dropin
+    for m in list(sys.modules):
+        if m in ("utils", "Tree", "Engine") or m.startswith(("Tree.", "Engine.")):
+            del sys.modules[m]
+    dropin.install()
+    try:
+        from Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG  # noqa: F401
+        from Engine.offload_engine import OffloadEngine  # noqa: F401
+        from Tree.GreedyTree import GreedyTree  # noqa: F401
+        from Tree.SpecTree import SpecTree
+        from utils import (_make_causal_mask, cuda_graph_for_residual, cuda_graph_for_sampling_argmax,  # noqa: F401
+                           cuda_graph_for_sampling_without_replacement, get_sampling_logits)
+        assert SpecTree.__module__ == "sequoia_amd.Tree.SpecTree"
+        import inspect
+        params = list(inspect.signature(SpecTree.__init__).parameters)
+        # the reference's constructor keywords, in order (Tree/SpecTree.py:8-28)
+        assert params[1:21] == ["draft_model_engine", "target_model_engine", "prefix", "temperature", "top_p",
+                                "draft_kv_len", "target_kv_len", "max_length", "device", "max_target_seq", "vocab_size",
+                                "grow_map", "attn_mask", "sequence", "new_tokens_buffer", "parents_buffer",
+                                "position_ids", "residual_graph", "sampling_callables", "sample_gather_indices"]
+    finally:
+        dropin.uninstall()
+
+
+def test_model_spec_errors_are_loud():
+    from sequoia_amd.Engine.Llama_model import parse_model_spec
+    with pytest.raises(FileNotFoundError):
+        parse_model_spec("meta-llama/Llama-2-7b-hf")
+    kind, (arch, opts) = parse_model_spec("random:JackFram/llama-68m:seed=3")
+    assert kind == "random" and arch == "JackFram/llama-68m" and opts["seed"] == "3"
