@@ -28,6 +28,90 @@ __device__ __forceinline__ uint32_t f16_to_ordered(half_t x) {
     return (b & 0x8000u) ? (uint16_t)~b : (uint16_t)(b | 0x8000u);
 }
 
+// Correctly rounded fp32 division for operands whose quotient cannot over/underflow (both here are
+// fp16-derived values): one v_rcp + two fma correction steps instead of the ~10-instruction IEEE
+// sequence.  Returns exactly RN(a / b) for normal a, b (Markstein): q1 = q0 + r*(a - q0*b).
+__device__ __forceinline__ float div_rn(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float r = __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);   // refine 1/b to <= 0.5 ulp-ish
+    const float q0 = a * r;
+    if (!(__builtin_fabsf(q0) < INFINITY)) return q0;   // +-inf / NaN numerators propagate like IEEE division
+    const float e = __builtin_fmaf(-q0, b, a);
+    return __builtin_fmaf(e, r, q0);
+}
+
+// exp / log on the hardware transcendental units (v_exp_f32 / v_log_f32 are base-2, 1 ulp) with the
+// base conversion carried in two-float precision, so the result stays within ~1.5 ulp of the exact
+// value -- the same class as libm's expf/logf (<= 1 ulp) at a third of the instructions.  The callers
+// round the result to fp16 (11 bits), where a 1-ulp fp32 difference is visible for ~1 element in 5000.
+__device__ __forceinline__ float exp_fast(float x) {           // x <= 0 in every caller
+#ifdef SQ_ACCURATE_TRANSCENDENTALS
+    return expf(x);
+#else
+    x = fmaxf(x, -104.0f);                                    // exp(-104) == 0 in fp32; avoids inf - inf below
+    const float t = x * 1.44269502e+00f;                      // hi part of x * log2(e)
+    const float lo = __builtin_fmaf(x, 1.44269502e+00f, -t) + x * 1.92596299e-08f;
+    const float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r, lo * 6.93147182e-01f, r);        // r * 2^lo, 2^lo ~ 1 + lo ln 2
+#endif
+}
+__device__ __forceinline__ float log_fast(float u) {           // u >= 0
+#ifdef SQ_ACCURATE_TRANSCENDENTALS
+    return logf(u);
+#else
+    const float l2 = __builtin_amdgcn_logf(u);                // log2(u); log2(0) = -inf
+    if (!(l2 > -INFINITY)) return l2;
+    const float hi = l2 * 6.93147182e-01f;
+    return __builtin_fmaf(l2, -1.90465421e-09f, hi + __builtin_fmaf(l2, 6.93147182e-01f, -hi));
+#endif
+}
+
+// DPP wave reductions: rotate within 16-lane rows (row_ror 8,4,2,1), then combine the four rows
+// through SGPRs (v_readlane).  ~10x cheaper than a ds_bpermute butterfly.  Result is wave-uniform.
+#define SQ_DPP_ROW_ROR(n) (0x120 + (n))
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
+#define SQ_STEP(n) { uint32_t w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, SQ_DPP_ROW_ROR(n), 0xf, 0xf, false); v = v > w ? v : w; }
+    SQ_STEP(8) SQ_STEP(4) SQ_STEP(2) SQ_STEP(1)
+#undef SQ_STEP
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ float wave_max_f32_dpp(float v) {
+#define SQ_STEP(n) { float w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), SQ_DPP_ROW_ROR(n), 0xf, 0xf, false)); v = fmaxf(v, w); }
+    SQ_STEP(8) SQ_STEP(4) SQ_STEP(2) SQ_STEP(1)
+#undef SQ_STEP
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_sum_f32_dpp(float v) {
+#define SQ_STEP(n) { float w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), SQ_DPP_ROW_ROR(n), 0xf, 0xf, false)); v += w; }
+    SQ_STEP(8) SQ_STEP(4) SQ_STEP(2) SQ_STEP(1)
+#undef SQ_STEP
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (a + b) + (c + d);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32_dpp(uint32_t v) {   // caller guarantees no overflow
+#define SQ_STEP(n) { v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, SQ_DPP_ROW_ROR(n), 0xf, 0xf, false); }
+    SQ_STEP(8) SQ_STEP(4) SQ_STEP(2) SQ_STEP(1)
+#undef SQ_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+// exact wave sum of 64 values < 2^32 as a 64-bit result: 16-bit limbs keep every partial sum < 2^23
+__device__ __forceinline__ unsigned long long wave_sum_u32_wide_dpp(uint32_t v) {
+    const uint32_t lo = wave_sum_u32_dpp(v & 0xffffu), hi = wave_sum_u32_dpp(v >> 16);
+    return ((unsigned long long)hi << 16) + lo;
+}
+
 // wave-level reductions over 64 lanes (all lanes get the result) ------------------------------
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
@@ -71,23 +155,23 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // is reusable after the call returns (two barriers inside).
 template <int NW>
 __device__ __forceinline__ float block_max_f32(float v, float* scratch) {
-    v = wave_max_f32(v);
+    v = wave_max_f32_dpp(v);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     if (l == 0) scratch[w] = v;
     __syncthreads();
     float r = scratch[l < NW ? l : 0];
-    r = wave_max_f32(r);
+    r = wave_max_f32_dpp(r);
     __syncthreads();
     return r;
 }
 template <int NW>
 __device__ __forceinline__ float block_sum_f32(float v, float* scratch) {
-    v = wave_sum_f32(v);
+    v = wave_sum_f32_dpp(v);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     if (l == 0) scratch[w] = v;
     __syncthreads();
     float r = (l < NW) ? scratch[l] : 0.0f;
-    r = wave_sum_f32(r);   // fixed order => deterministic
+    r = wave_sum_f32_dpp(r);   // fixed order => deterministic
     __syncthreads();
     return r;
 }

@@ -4,8 +4,9 @@
 // register copy.  Rounding points follow the fp16 torch expression of the reference
 // (utils.py:10-18): y = h(x/T), q = h(exp(y-max)/sum), lu = h(log u), key = h(lu/q).
 //
-// Top-k = k rounds of block-wide arg-max on a 32-bit composite (ordered fp16 key << 16 |
-// 0xffff - local order), ties resolved to the lower token id.
+// Top-k = two-level tournament on 32-bit composites (ordered fp16 key << 16 | 0xffff - token id):
+// per-wave DPP arg-max rounds, then one wave merges the 16 candidate lists.  Ties resolve to the
+// lower token id.
 #include "common.h"
 
 #define SAMP_THREADS 1024
@@ -21,7 +22,6 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
                    int64_t* __restrict__ out, const int32_t* __restrict__ branch, const int32_t* __restrict__ out_off) {
     constexpr int CH = EPT / 8;
     __shared__ float s_f[SAMP_WAVES];
-    __shared__ uint32_t s_u[SAMP_WAVES];
     const int t = threadIdx.x;
     const int r = blockIdx.x;
     const int64_t row = row_ids ? (int64_t)row_ids[r] : (int64_t)r;
@@ -48,7 +48,7 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float yy = -INFINITY;
-                if (e0 + j < vocab) yy = (float)(half_t)((float)v[j] / temperature);
+                if (e0 + j < vocab) yy = (float)(half_t)div_rn((float)v[j], temperature);
                 y[c * 8 + j] = yy;
                 lmax = fmaxf(lmax, yy);
             }
@@ -57,7 +57,7 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
         float lsum = 0.f;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-            y[i] = expf(y[i] - mx);          // exp(-inf) = 0 for padding
+            y[i] = exp_fast(y[i] - mx);          // exp(-inf) = 0 for padding
             lsum += y[i];
         }
         const float z = block_sum_f32<SAMP_WAVES>(lsum, s_f);
@@ -69,9 +69,10 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
             if (e0 < vocab) uv = *(const half8*)(u + e0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const half_t q = (half_t)(y[c * 8 + j] / z);
-                const half_t lu = (half_t)logf((float)uv[j]);
-                key[c * 8 + j] = (half_t)((float)lu / (float)q);
+                const half_t q = (half_t)div_rn(y[c * 8 + j], z);
+                const half_t lu = (half_t)log_fast((float)uv[j]);
+                // lu / 0 = -inf (lu < 0 always: u < 1); otherwise the correctly rounded quotient
+                key[c * 8 + j] = (q == (half_t)0.0f) ? (half_t)(-INFINITY) : (half_t)div_rn((float)lu, (float)q);
             }
         }
     } else {
@@ -85,12 +86,66 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
         }
     }
 
-    // composite = ordered key << 16 | (0xffff - position), position = c*8+j local to the thread:
-    // within a thread a lower position is a lower token id; across threads ties are resolved by
-    // (chunk, thread) below, so the block-level composite uses the true token id when it fits.
-    // Token ids need 17 bits for vocab up to 131072; we therefore reduce on
-    // (ordered key << 32 | ~token_id) only when two candidates tie on the key... simpler and
-    // exact: a 64-bit composite.  The reduction cost is dominated by the barrier, not the width.
+    // ---- top-k: two-level tournament -----------------------------------------------------------
+    // composite = ordered fp16 key << 16 | (0xffff - token id): the maximum is the largest key and,
+    // inside an exact tie, the lowest token id.  (Token ids need 16 bits: vocab <= 65536; wider
+    // vocabularies take the 64-bit path below.)  Level 1: every wave extracts its own top-n_out with
+    // DPP arg-max rounds (no barriers); level 2: wave 0 merges the 16 x n_out candidates.
+    if (vocab <= 65536) {
+        __shared__ uint32_t s_cand[SAMP_WAVES * SQ_MAX_TOPK];
+        const int lane = t & 63, wave = t >> 6;
+        // composites are built once; a retired element becomes 0 and each round is one
+        // compare-select-max sweep over the thread's registers
+        uint32_t comp[EPT];
+        uint32_t best = 0u;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = elem_index(i >> 3, t, i & 7);
+            comp[i] = (e < vocab) ? ((f16_to_ordered(key[i]) << 16) | (0xffffu - (uint32_t)e)) : 0u;
+            best = comp[i] > best ? comp[i] : best;
+        }
+        for (int s = 0; s < n_out; ++s) {
+            const uint32_t win = wave_max_u32_dpp(best);
+            if (lane == 0) s_cand[wave * SQ_MAX_TOPK + s] = win;
+            if (win == best && win != 0u) {          // this lane owns the winner (composites are unique)
+                best = 0u;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    comp[i] = (comp[i] == win) ? 0u : comp[i];
+                    best = comp[i] > best ? comp[i] : best;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // 16 sorted lists of n_out candidates; lane l owns candidates l, l+64, ...
+            constexpr int CPL = SAMP_WAVES * SQ_MAX_TOPK / 64;     // 32
+            uint32_t c[CPL];
+            const int total = SAMP_WAVES * n_out;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int idx = j * 64 + lane;                     // (wave w, rank s) = (idx / n_out, idx % n_out)
+                c[j] = idx < total ? s_cand[(idx / n_out) * SQ_MAX_TOPK + (idx % n_out)] : 0u;
+            }
+            uint32_t lb = 0u;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) lb = c[j] > lb ? c[j] : lb;
+            for (int s = 0; s < n_out; ++s) {
+                const uint32_t win = wave_max_u32_dpp(lb);
+                if (lane == 0) dst[s] = (win == 0u) ? 0 : (int64_t)(0xffffu - (win & 0xffffu));
+                if (win == lb && win != 0u) {
+                    lb = 0u;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        if (c[j] == win) c[j] = 0u;
+                        lb = c[j] > lb ? c[j] : lb;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- wide-vocabulary path: k rounds of block-wide arg-max on 64-bit composites ------------------
     unsigned long long best;
     auto local_best = [&](uint32_t removed_lo, uint32_t removed_hi, uint32_t removed_2, uint32_t removed_3) {
         unsigned long long b = 0ull;
@@ -115,7 +170,6 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
         const uint32_t e = 0xffffffffu - (uint32_t)(win & 0xffffffffu);
         if (t == 0) dst[s] = (win == 0ull) ? 0 : (int64_t)e;
         if (win == best && win != 0ull) {
-            // this thread owns the winner: retire it and recompute the local best
             const int c = (int)(e >> 3) / SAMP_THREADS;
             const int i = c * 8 + (int)(e & 7);
             if (i < 32) rm0 |= 1u << i;
@@ -125,7 +179,6 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
             best = local_best(rm0, rm1, rm2, rm3);
         }
     }
-    (void)s_u;
 }
 
 template <bool WOR>

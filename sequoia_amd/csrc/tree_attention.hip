@@ -3,11 +3,14 @@
 // (no dense mask in HBM) or, for drop-in callers, from the reference's dense additive mask.
 //
 // Decomposition (latency-bound problem: per layer only ~6 MB of K/V/Q/O, 0.5 GFLOP):
-//   grid  = (ceil(q_len / 16), n_heads): one workgroup per (16-query tile, head) -> 256
-//           workgroups for the 7B verify (q = 128, H = 32), one per CU.
-//   block = 4 waves; wave w walks the 32-key chunks w, w+4, ... of the KV range (split-KV inside
-//           the workgroup) with its own online-softmax state, and the four partial results are
-//           merged through LDS at the end.
+//   grid  = one workgroup per (16-query tile, head) -> 256 workgroups for the 7B verify (q = 128,
+//           H = 32), one per CU.  The linear block id is decoded XCD-aware: the dispatcher places
+//           block b on XCD b % 8, so all query tiles of a head are given ids with the same b % 8 and
+//           the head's K/V is fetched into ONE XCD's L2 instead of all eight.
+//   block = 8 waves; wave w walks the 32-key chunks w, w+8, ... of the KV range (split-KV inside
+//           the workgroup, <= 2 chunks per wave up to 512 keys, next chunk's K/V prefetched into
+//           registers while the current one is computed) with its own online-softmax state; the
+//           partial results are merged through LDS at the end.
 // Per 32-key chunk and wave:
 //   S^T = K Q^T   (A = K rows straight from HBM as 16-byte fragment loads, B = Q, held in VGPRs)
 //         -> lane (q = lane&15, g = lane>>4) holds keys {16t + 4g + r}: exactly the A-operand
@@ -18,7 +21,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define ATT_WAVES 4
+#define ATT_WAVES 8
 #define ATT_THREADS (ATT_WAVES * 64)
 #define ATT_BM 16      // queries per workgroup
 #define ATT_BK 32      // keys per chunk
@@ -51,7 +54,7 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
     constexpr int DSTEPS = D / 32;       // MFMA k-steps for S^T
     constexpr int NT = D / 16;           // 16-wide output column tiles
     constexpr int VSTRIDE = D + 8;       // halves; +16 B keeps ds_write_b128 aligned and de-phases banks
-    constexpr int V_TILE = ATT_BK * VSTRIDE;                    // halves per wave
+    constexpr int V_TILE = 2 * ATT_BK * VSTRIDE;                // halves per wave: V tile then K tile
     constexpr int O_TILE = ATT_BM * D;                          // floats per wave
     // LDS: V staging (per wave) is reused for the cross-wave merge of O.
     constexpr int LDS_BYTES_V = ATT_WAVES * V_TILE * 2;
@@ -65,8 +68,13 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int qc = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * ATT_BM;
-    const int head = blockIdx.y;
+    // XCD-aware decode: b % 8 selects the XCD; heads are dealt to XCDs round-robin, every query
+    // tile of a head shares its XCD (pure speed hint: any placement is correct).
+    const int n_tiles = (P.q_len + ATT_BM - 1) / ATT_BM;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int head = xcd + 8 * (jj / n_tiles);
+    if (head >= P.n_heads) return;           // uniform per block
+    const int q0 = (jj % n_tiles) * ATT_BM;
     const int kvh = head / (P.n_heads / P.h_kv);
     const half_t* kbase = P.k + (size_t)kvh * P.m * D;
     const half_t* vbase = P.v + (size_t)kvh * P.m * D;
@@ -104,31 +112,54 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
 
     half_t* my_v = lds_v + wave * V_TILE;
     const int n_chunks = (P.kv_len + ATT_BK - 1) / ATT_BK;
-    for (int ch = wave; ch < n_chunks; ch += ATT_WAVES) {
-        const int key0 = ch * ATT_BK;
-        // ---- V chunk -> LDS (row-major, padded) -----------------------------------------------
-        {
-            constexpr int CPR = D / 8;                      // 16-byte chunks per row
-            constexpr int ITER = ATT_BK * CPR / 64;
+    constexpr int CPR = D / 8;                      // 16-byte chunks per K/V row
+    constexpr int VITER = ATT_BK * CPR / 64;        // 16-byte V loads per lane and chunk
+
+    // K fragments (A operand: lane (key = qc, g) holds K[key][32 s + 8 g .. +8]) and the V rows of a
+    // chunk, straight from HBM/L2 into registers.  Two register sets: the next chunk is in flight
+    // while the current one is computed.
+    u32x4 kr_cur[VITER], kr_nxt[VITER];
+    u32x4 vr_cur[VITER], vr_nxt[VITER];
+    half_t* my_k = my_v + ATT_BK * VSTRIDE;
+    // Both K and V rows are fetched as whole 16-byte-per-lane row segments (a wave instruction
+    // covers 4 (D=128) or 8 (D=64) complete rows = full cache lines) and staged through the wave's
+    // private LDS tiles; fragment-shaped global loads (16 rows x 64 B per instruction) cost ~2x.
+    auto issue_loads = [&](int chunk, u32x4 (&kr)[VITER], u32x4 (&vr)[VITER]) {
+        const int key0 = chunk * ATT_BK;
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int idx = it * 64 + lane;
-                const int r = idx / CPR, c = idx % CPR;
-                int kr = key0 + r; if (kr >= P.kv_len) kr = P.kv_len - 1;
-                const u32x4 val = *(const u32x4*)(vbase + (size_t)kr * D + c * 8);
-                *(u32x4*)(my_v + r * VSTRIDE + c * 8) = val;
-            }
+        for (int it = 0; it < VITER; ++it) {
+            const int idx = it * 64 + lane;
+            const int r = idx / CPR, c = idx % CPR;
+            int row = key0 + r; if (row >= P.kv_len) row = P.kv_len - 1;
+            kr[it] = *(const u32x4*)(kbase + (size_t)row * D + c * 8);
+            vr[it] = *(const u32x4*)(vbase + (size_t)row * D + c * 8);
         }
-        // ---- S^T = K Q^T ------------------------------------------------------------------------
+    };
+
+    int ch = wave;
+    if (ch < n_chunks) issue_loads(ch, kr_cur, vr_cur);
+    for (; ch < n_chunks; ch += ATT_WAVES) {
+        const int key0 = ch * ATT_BK;
+        const bool has_next = ch + ATT_WAVES < n_chunks;
+        if (has_next) issue_loads(ch + ATT_WAVES, kr_nxt, vr_nxt);
+        // ---- K, V chunk -> wave-private LDS tiles (row-major, padded) ---------------------------------
+#pragma unroll
+        for (int it = 0; it < VITER; ++it) {
+            const int idx = it * 64 + lane;
+            *(u32x4*)(my_k + (idx / CPR) * VSTRIDE + (idx % CPR) * 8) = kr_cur[it];
+            *(u32x4*)(my_v + (idx / CPR) * VSTRIDE + (idx % CPR) * 8) = vr_cur[it];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- S^T = K Q^T: A fragment = K[key = 16t + qc][32s + 8g .. +8] via ds_read_b128 (row stride
+        //      D+8 halves = 68 dwords -> the 16 lanes of a group hit 16 distinct 16-byte bank slots) ------
         floatx4 s_acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            int kr = key0 + t * 16 + qc; if (kr >= P.kv_len) kr = P.kv_len - 1;
-            const half_t* krow = kbase + (size_t)kr * D;
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < DSTEPS; ++s) {
-                const half8 kf = *(const half8*)(krow + s * 32 + g * 8);
+                const half8 kf = *(const half8*)(my_k + (t * 16 + qc) * VSTRIDE + s * 32 + g * 8);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], acc, 0, 0, 0);
             }
             s_acc[t] = acc;
@@ -208,9 +239,13 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
             o_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o, 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
+        if (has_next) {
+#pragma unroll
+            for (int it = 0; it < VITER; ++it) { kr_cur[it] = kr_nxt[it]; vr_cur[it] = vr_nxt[it]; }
+        }
     }
 
-    // ---- merge the four waves ---------------------------------------------------------------------
+    // ---- merge the waves ---------------------------------------------------------------------
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     __syncthreads();                       // everyone is done with the V staging area
@@ -222,7 +257,7 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
             lds_o[(wave * ATT_BM + g * 4 + r) * D + nt * 16 + qc] = o_acc[nt][r];
     __syncthreads();
     {
-        constexpr int EPT_O = ATT_BM * D / ATT_THREADS;       // 8 (D=128) or 4 (D=64)
+        constexpr int EPT_O = ATT_BM * D / ATT_THREADS;       // 4 (D=128) or 2 (D=64)
         const int row = tid / (D / EPT_O);
         const int col = (tid % (D / EPT_O)) * EPT_O;
         float mw[ATT_WAVES], lw[ATT_WAVES], mmax = -INFINITY;
@@ -254,11 +289,16 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o8[e] = (half_t)res[e];
                 *(half8*)dst = o8;
-            } else {
+            } else if constexpr (EPT_O == 4) {
                 half4 o4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o4[e] = (half_t)res[e];
                 *(half4*)dst = o4;
+            } else {
+                static_assert(EPT_O == 2, "unexpected tile/thread ratio");
+                half2v o2;
+                o2[0] = (half_t)res[0]; o2[1] = (half_t)res[1];
+                *(half2v*)dst = o2;
             }
         }
     }
@@ -289,7 +329,8 @@ extern "C" int sq_tree_attention_f16(const void* q, const void* k_layer, const v
         return SQ_EINVAL;
     }
     if (q_len == 0) return SQ_OK;
-    dim3 grid((q_len + ATT_BM - 1) / ATT_BM, n_heads), block(ATT_THREADS);
+    const int n_tiles = (q_len + ATT_BM - 1) / ATT_BM;
+    dim3 grid(8 * ((n_heads + 7) / 8) * n_tiles), block(ATT_THREADS);
     static const bool no_tr = getenv("SQ_ATTN_NO_TR") != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (d == 128) {

@@ -54,7 +54,8 @@ __device__ __forceinline__ half_t grid_sum_to_f16(unsigned long long total) {
 template <int EPT>
 __device__ __forceinline__ void row_softmax_f16(const half_t* __restrict__ x, int vocab, float temperature, int t,
                                                 half_t (&p)[EPT], float* s_f) {
-    float y[EPT];
+    // p first holds y = h(x / T) (fp16), then the probabilities; the exponential is evaluated twice
+    // (sum pass, normalise pass) rather than parked in EPT fp32 registers.
     float lmax = -INFINITY;
 #pragma unroll
     for (int c = 0; c < EPT / 8; ++c) {
@@ -63,22 +64,38 @@ __device__ __forceinline__ void row_softmax_f16(const half_t* __restrict__ x, in
         if (e0 < vocab) v = *(const half8*)(x + e0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float yy = -INFINITY;
-            if (e0 + j < vocab) yy = (float)(half_t)((float)v[j] / temperature);
-            y[c * 8 + j] = yy;
-            lmax = fmaxf(lmax, yy);
+            const half_t yy = (e0 + j < vocab) ? (half_t)div_rn((float)v[j], temperature) : (half_t)(-INFINITY);
+            p[c * 8 + j] = yy;
+            lmax = fmaxf(lmax, (float)yy);
         }
     }
     const float mx = block_max_f32<VER_WAVES>(lmax, s_f);
     float lsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        y[i] = expf(y[i] - mx);
-        lsum += y[i];
-    }
+    for (int i = 0; i < EPT; ++i) lsum += exp_fast((float)p[i] - mx);
     const float z = block_sum_f32<VER_WAVES>(lsum, s_f);
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) p[i] = (half_t)(y[i] / z);
+    for (int i = 0; i < EPT; ++i) p[i] = (half_t)div_rn(exp_fast((float)p[i] - mx), z);
+}
+
+// one block-wide reduction of three quantities at once: exact integer sum, float max, float sum
+struct Red3 { unsigned long long isum; float fmax; float fsum; };
+__device__ __forceinline__ Red3 block_red3(uint32_t isum32, float fmx, float fsum, unsigned long long* s_u,
+                                           float* s_m, float* s_s) {
+    unsigned long long isum = wave_sum_u32_wide_dpp(isum32);     // per-thread partial <= EPT * 2^24 < 2^32
+    fmx = wave_max_f32_dpp(fmx);
+    fsum = wave_sum_f32_dpp(fsum);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) { s_u[w] = isum; s_m[w] = fmx; s_s[w] = fsum; }
+    __syncthreads();
+    Red3 r;
+    r.isum = 0ull; r.fmax = -INFINITY; r.fsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VER_WAVES; ++i) {        // fixed order => deterministic
+        r.isum += s_u[i]; r.fmax = fmaxf(r.fmax, s_m[i]); r.fsum += s_s[i];
+    }
+    __syncthreads();
+    return r;
 }
 
 template <int EPT>
@@ -89,6 +106,8 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
                     int vocab, int gt, float temperature, uint32_t u24, void* ws_raw) {
     constexpr int CH = EPT / 8;
     __shared__ float s_f[VER_WAVES];
+    __shared__ float s_m[VER_WAVES];
+    __shared__ float s_s[VER_WAVES];
     __shared__ unsigned long long s_u[VER_WAVES];
     __shared__ float s_tok[2];            // e[tok], p[tok] of the child under test
     __shared__ unsigned long long s_scan[VER_WAVES];
@@ -103,59 +122,84 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
     const int c0 = child_off[node], nc = child_off[node + 1] - c0;
     int accepted = -1, nrej = 0, nan_flag = 0;
     if (nc > 0) {
-        half_t yd[EPT];                   // h(draft_logits / T); rejected tokens become -inf
+        // draft side: yd = h(draft_logits / T) (rejected tokens become -inf), q = h(exp(yd - mx) / z).
+        // Only p and yd (fp16, 16 VGPRs each) stay live across the child loop; exponentials are
+        // recomputed per pass (7 instructions) instead of being kept in 32 more registers.
+        half_t yd[EPT];
         const half_t* xd = draft_logits + (size_t)node * vocab;
+        float lmax = -INFINITY;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int e0 = v_elem(c, t, 0);
             half8 v;
             if (e0 < vocab) v = *(const half8*)(xd + e0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                yd[c * 8 + j] = (e0 + j < vocab) ? (half_t)((float)v[j] / temperature) : (half_t)(-INFINITY);
+            for (int j = 0; j < 8; ++j) {
+                const half_t yy = (e0 + j < vocab) ? (half_t)div_rn((float)v[j], temperature) : (half_t)(-INFINITY);
+                yd[c * 8 + j] = yy;
+                lmax = fmaxf(lmax, (float)yy);
+            }
         }
+        float mx = block_max_f32<VER_WAVES>(lmax, s_f);
+        float lsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) lsum += exp_fast((float)yd[i] - mx);
+        float z = block_sum_f32<VER_WAVES>(lsum, s_f);
+
         for (int jc = 0; jc < nc; ++jc) {
             const int child = child_ids[c0 + jc];
             const int slot = child + gt - 1;
             const int tok = (int)tokens[slot];
             const half_t rr = r16[slot];
-            // q = softmax(yd): max, exp, sum
-            float lmax = -INFINITY;
+            // element tok lives in thread (tok/8) % THREADS at register (tok/8/THREADS)*8 + tok%8:
+            // a scalar index compare instead of 32 per-thread element ids held in registers
+            const bool mine = t == ((tok >> 3) & (VER_THREADS - 1));
+            const int tok_local = ((tok >> 3) / VER_THREADS) * 8 + (tok & 7);
+            // broadcast e[tok], p[tok] from the owning thread
 #pragma unroll
-            for (int i = 0; i < EPT; ++i) lmax = fmaxf(lmax, (float)yd[i]);
-            const float mx = block_max_f32<VER_WAVES>(lmax, s_f);
-            float e[EPT];
-            float lsum = 0.f;
-#pragma unroll
-            for (int i = 0; i < EPT; ++i) {
-                e[i] = expf((float)yd[i] - mx);
-                lsum += e[i];
-                if (v_elem(i >> 3, t, i & 7) == tok) { s_tok[0] = e[i]; s_tok[1] = (float)p[i]; }
-            }
-            const float z = block_sum_f32<VER_WAVES>(lsum, s_f);   // barriers inside publish s_tok
-            const half_t q_tok = (half_t)(s_tok[0] / z);
+            for (int i = 0; i < EPT; ++i)
+                if (mine && i == tok_local) { s_tok[0] = exp_fast((float)yd[i] - mx); s_tok[1] = (float)p[i]; }
+            __syncthreads();
+            const half_t q_tok = (half_t)div_rn(s_tok[0], z);
             const half_t p_tok = (half_t)s_tok[1];
             const half_t rq = (half_t)((float)rr * (float)q_tok);
             const bool ok = (tok >= 0 && tok < vocab) && (p_tok > rq);   // strict, Tree/SpecTree.py:152
             if (ok) { accepted = child; break; }
             // reject: p <- relu(p - q) / sum(relu(p - q));  draft_logits[tok] <- -65504 (=> q[tok] = 0)
-            unsigned long long lint = 0ull;
+            uint32_t lint = 0u;
+            float nmax = -INFINITY, nsum = 0.f;
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
-                const half_t q = (half_t)(e[i] / z);
+                const float ei = exp_fast((float)yd[i] - mx);
+                const half_t q = (half_t)div_rn(ei, z);
                 half_t di = (half_t)((float)p[i] - (float)q);
                 di = di > (half_t)0.0f ? di : (half_t)0.0f;      // relu_; NaN p stays out (compares false)
                 p[i] = di;                                       // p now holds the unnormalised residual
-                lint += (unsigned long long)(uint32_t)((float)di * 16777216.0f);
-                if (v_elem(i >> 3, t, i & 7) == tok) yd[i] = (half_t)(-INFINITY);
+                lint += (uint32_t)((float)di * 16777216.0f);
+                if (mine && i == tok_local) {
+                    yd[i] = (half_t)(-INFINITY);
+                } else {
+                    nmax = fmaxf(nmax, (float)yd[i]);
+                    nsum += ei;
+                }
             }
-            const unsigned long long tot = block_sum_u64<VER_WAVES>(lint, s_u);
-            const half_t s16 = grid_sum_to_f16(tot);
-            if (tot == 0ull) nan_flag = 1;                       // 0/0 -> NaN residual (utils.py:7)
+            const Red3 red = block_red3(lint, nmax, nsum, s_u, s_m, s_s);   // also orders the s_tok reads above
+            const half_t s16 = grid_sum_to_f16(red.isum);
+            if (red.isum == 0ull) nan_flag = 1;                  // 0/0 -> NaN residual (utils.py:7)
+            const float sf = (float)s16;
 #pragma unroll
-            for (int i = 0; i < EPT; ++i) p[i] = (half_t)((float)p[i] / (float)s16);
+            for (int i = 0; i < EPT; ++i) p[i] = nan_flag ? (half_t)NAN : (half_t)div_rn((float)p[i], sf);
             nrej = jc + 1;
             if (nan_flag) break;          // every later comparison with NaN is false: all rejected
+            if (red.fmax != mx) {         // the removed token was the maximum: rebase the exponentials
+                mx = red.fmax;
+                lsum = 0.f;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) lsum += exp_fast((float)yd[i] - mx);
+                z = block_sum_f32<VER_WAVES>(lsum, s_f);
+            } else {
+                z = red.fsum;
+            }
         }
         if (nan_flag) nrej = nc;
     }
@@ -163,19 +207,29 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
     int bonus = -1;
     if (accepted < 0 && !nan_flag) {
         // exact inverse CDF on the 2^-24 grid, element-index order = (chunk, thread, j)
-        unsigned long long csum[CH];
+        uint32_t csum[CH];                   // per-thread sum of one 8-element chunk: <= 8 * 2^24
         unsigned long long total = 0ull, base = 0ull;
+        __shared__ unsigned long long s_ct[VER_WAVES][EPT / 8];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            unsigned long long s = 0ull;
+            uint32_t sv = 0u;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (v_elem(c, t, j) < vocab) s += (unsigned long long)(uint32_t)((float)p[c * 8 + j] * 16777216.0f);
-            csum[c] = s;
+                if (v_elem(c, t, j) < vocab) sv += (uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+            csum[c] = sv;
+            const unsigned long long wsum = wave_sum_u32_wide_dpp(sv);
+            if ((t & 63) == 0) s_ct[t >> 6][c] = wsum;
         }
+        __syncthreads();
         unsigned long long ctot[CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) { ctot[c] = block_sum_u64<VER_WAVES>(csum[c], s_u); total += ctot[c]; }
+        for (int c = 0; c < CH; ++c) {
+            unsigned long long acc = 0ull;
+#pragma unroll
+            for (int w2 = 0; w2 < VER_WAVES; ++w2) acc += s_ct[w2][c];
+            ctot[c] = acc;
+            total += acc;
+        }
         if (total > 0ull) {
             const unsigned long long thr = (__umul64hi((unsigned long long)u24, total) << 40) |
                                            (((unsigned long long)u24 * total) >> 24);
@@ -189,8 +243,8 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             }
             unsigned long long mine = 0ull;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) if (c == cstar) mine = csum[c];
-            // inclusive scan of `mine` over the 1024 threads
+            for (int c = 0; c < CH; ++c) if (c == cstar) mine = (unsigned long long)csum[c];
+            // inclusive scan of `mine` over the block's threads
             unsigned long long inc = mine;
             const int lane = t & 63, w = t >> 6;
 #pragma unroll
