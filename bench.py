@@ -184,7 +184,7 @@ def kernel_rooflines(cfg, loop, device):
         toks = torch.randint(3, V, (M,), device=device)
         r = torch.rand(M, device=device).half()
         ws = ops.verify_workspace(n, device)
-        rr = torch.zeros(64, dtype=torch.int32, device=device)
+        rr = torch.zeros(64 + n, dtype=torch.int32, device=device)
         dl2 = dl.clone()
 
         def ver():
@@ -213,17 +213,18 @@ def kernel_rooflines(cfg, loop, device):
     return res
 
 
-def cpu_baseline(cfg, n_steps=2):
+def cpu_baseline(cfg, n_steps=1, pair="calibrated"):
     """The CPU path timed on this box's host cores: the same host loop with the numpy oracle ops
     (oracle/ops_adapter.py) and PyTorch CPU GEMMs, fp16 like the reference, on a bounded sample
-    (n_steps speculation steps of the first prompt; the first includes the 255-token prefill)."""
+    (n_steps speculation steps of the first prompt; the first includes the 255-token prefill),
+    same synthetic weight pair as the GPU run."""
     from oracle.ops_adapter import OracleOps
     from sequoia_amd import ops as ops_mod
     prev = ops_mod._OPS
     ops_mod.set_ops_for_testing(OracleOps())
     try:
         t0 = time.perf_counter()
-        draft, target, gm = build(cfg, "cpu", "random")
+        draft, target, gm = build(cfg, "cpu", pair)
         build_s = time.perf_counter() - t0
         loop = Loop.__new__(Loop)
         from sequoia_amd.Tree.GreedyTree import GreedyTree
@@ -265,7 +266,8 @@ def main():
     ap.add_argument("--pair", default="calibrated", choices=["calibrated", "random"])
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="leave PyTorch's GEMM algorithm choice at its default")
+    ap.add_argument("--cpu-steps", type=int, default=1)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -280,6 +282,10 @@ def main():
     torch.manual_seed(17 + rank)
 
     cfg = MODELS[args.config]
+    gemm_tuned = False
+    if not args.no_gemm_tuning:
+        from sequoia_amd import gemm_tuning
+        gemm_tuned = gemm_tuning.enable()
     draft, target, gm = build(cfg, device, args.pair)
     prompts = load_prompts()[rank::world] if world > 1 else load_prompts()
     loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs)
@@ -313,7 +319,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
-                cpu = cpu_baseline(cfg, args.cpu_steps)
+                cpu = cpu_baseline(cfg, args.cpu_steps, args.pair)
             except Exception as e:  # the baseline is a report, never the measured path
                 cpu = dict(value=None, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
                            sample=f"failed: {type(e).__name__}: {e}")
@@ -324,7 +330,9 @@ def main():
                                          f"({args.pair} random-init weights), growmap {cfg['growmap']} "
                                          f"({gm.size}-node tree), T=0.6, top_p=1.0, M={cfg['M']}, 128-token c4_small "
                                          f"prompts, generate to 256",
-                                parallelism="replicas" if world > 1 else "single", graphs=not args.no_graphs),
+                                parallelism="replicas" if world > 1 else "single", graphs=not args.no_graphs,
+                                gemm="torch TunableOp (hipBLASLt/rocBLAS solution picked per shape)" if gemm_tuned
+                                else "torch default"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs,
                     roofline=roof, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(line))

@@ -36,7 +36,8 @@ extern "C" {
 #define SQ_MAX_TREE      512 /* max tree nodes (ancestor bitmask = 8 x u64 words)           */
 #define SQ_MASK_WORDS(n) (((n) + 63) / 64)
 #define SQ_MAX_TOPK      128 /* max children per parent / samples per row                   */
-#define SQ_RESULT_INTS   64  /* size of the int32 step-result record, see below             */
+#define SQ_RESULT_INTS   64  /* header of the int32 step-result record, see below; the buffer
+                                passed as d_result holds SQ_RESULT_INTS + n_tree ints            */
 
 /* Step-result record written by sq_verify_* (device memory, int32[SQ_RESULT_INTS]).        */
 #define SQ_RES_ACCEPT_LEN 0  /* a = len(accept_list) = gt + #accepted tree nodes            */
@@ -46,7 +47,8 @@ extern "C" {
 #define SQ_RES_REASON     4  /* 0 none, 1 EOS token accepted, 2 NaN residual                */
 #define SQ_RES_GT         5  /* echo of the ground_truth_len the step ran with              */
 #define SQ_RES_LAST_NODE  6  /* tree-local id of the node the walk stopped at               */
-#define SQ_RES_SLOTS      8  /* [8, 8+N_TREE): absolute slots of the accepted tree nodes    */
+#define SQ_RES_SLOTS      8  /* [8, 8+min(N_TREE,56)): absolute slots of the accepted nodes  */
+/* [SQ_RESULT_INTS, SQ_RESULT_INTS + N_TREE): the complete list of accepted slots (ascending).  */
 
 /* ---- library ---------------------------------------------------------------------------- */
 int         sq_version(void);                 /* 10000*major + 100*minor + patch            */

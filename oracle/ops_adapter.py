@@ -93,8 +93,10 @@ class OracleOps:
         r[:] = 0
         r[0], r[1], r[2], r[3], r[4], r[5], r[6] = (res["accept_len"], res["n_tree"], res["bonus"], res["terminal"],
                                                     res["reason"], res["gt"], res["last_node"])
-        for j, s in enumerate(res["slots"][:56]):
-            r[8 + j] = s
+        for j, s in enumerate(res["slots"]):
+            if j < 56:
+                r[8 + j] = s
+            r[64 + j] = s
 
     def verify_stochastic(self, target_logits, draft_logits, tokens, r, child_off, child_ids, n_tree, gt, temperature,
                           u24, workspace, result):

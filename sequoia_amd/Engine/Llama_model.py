@@ -152,10 +152,21 @@ class LlamaWeights:
         gen = torch.Generator(device=device)
         ws, r = dims.tp_world, dims.tp_rank
 
+        on_cpu = str(device) == "cpu"
+
         def normal(shape, tag):
             # one stream per (tensor, rank-independent) so that shards of different ranks are
             # slices of the same full matrix
             gen.manual_seed(seed * 1000003 + tag)
+            numel = 1
+            for d_ in shape:
+                numel *= d_
+            if on_cpu and numel > (1 << 22):
+                # CPU (baseline timing only): fp16 normal_ is single-threaded and takes minutes for
+                # 7B parameters; tile a 4M-element N(0, 0.02) pool instead (memcpy speed)
+                pool = torch.empty(1 << 22, dtype=torch.float32).normal_(0.0, 0.02, generator=gen).to(dtype)
+                reps = (numel + pool.numel() - 1) // pool.numel()
+                return pool.repeat(reps)[:numel].view(shape)
             return torch.empty(shape, dtype=dtype, device=device).normal_(0.0, 0.02, generator=gen)
 
         h, inter, d = dims.hidden_size, dims.intermediate_size, dims.head_dim

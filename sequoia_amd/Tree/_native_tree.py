@@ -85,7 +85,7 @@ class NativeTree(Tree):
             self.bonus_u24 = [int(x) for x in bonus_uniforms]
         self.step_idx = 0
         self.verify_ws = self.ops.verify_workspace(n, self.device)
-        self.result = torch.zeros(SQ_RESULT_INTS, dtype=torch.int32, device=self.device)
+        self.result = torch.zeros(SQ_RESULT_INTS + n, dtype=torch.int32, device=self.device)
         self.seq_to_use = list(range(self.max_length))
         self.target_logits = None
 
@@ -159,16 +159,14 @@ class NativeTree(Tree):
         n_acc = int(res[SQ_RES_N_TREE])
         terminal = bool(res[SQ_RES_TERMINAL])
         self.last_result = res
-        accept_list = self.seq_to_use[:gt] + [int(s) for s in res[SQ_RES_SLOTS:SQ_RES_SLOTS + min(n_acc, SQ_RESULT_INTS - SQ_RES_SLOTS)]]
+        accept_list = self.seq_to_use[:gt] + [int(s) for s in res[SQ_RESULT_INTS:SQ_RESULT_INTS + n_acc]]
         if benchmark:
             _sync(self.device); t3 = time.time()
         self.step_idx += 1
 
         if self._compact_when_terminal or not terminal:
-            slots, count = self.result[SQ_RES_SLOTS:], self.result[SQ_RES_N_TREE:SQ_RES_N_TREE + 1]
-            max_count = min(n_acc, SQ_RESULT_INTS - SQ_RES_SLOTS)
-            if n_acc > SQ_RESULT_INTS - SQ_RES_SLOTS:        # chains deeper than the record: path lives in the workspace
-                raise NotImplementedError("accepted paths longer than 56 nodes")
+            slots, count = self.result[SQ_RESULT_INTS:], self.result[SQ_RES_N_TREE:SQ_RES_N_TREE + 1]
+            max_count = n_acc
             self.draft_model_engine.engine.kv_cache.compact_from_device(slots, count, max_count, gt, accept_length)
             self.target_model_engine.engine.kv_cache.compact_from_device(slots, count, max_count, gt, accept_length)
 

@@ -316,6 +316,7 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
         node = child;
         ws.path[n_acc] = node;
         if (n_acc < SQ_RESULT_INTS - SQ_RES_SLOTS) result[SQ_RES_SLOTS + n_acc] = node + gt - 1;
+        result[SQ_RESULT_INTS + n_acc] = node + gt - 1;         // full list (chains deeper than the header)
         ++n_acc;
         const int64_t tk = tokens[node + gt - 1];
         if (tk == 0 || tk == 2) { terminal = 1; reason = 1; break; }   // Tree/SpecTree.py:208

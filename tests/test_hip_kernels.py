@@ -243,7 +243,7 @@ def _run_verify_stochastic(ops, target, draft, tokens, r16, succ, gt, T, u24):
     off, ids = csr(succ)
     d_tokens, d_draft = dev(tokens), dev(draft)
     ws = ops.verify_workspace(n, DEV)
-    res = torch.zeros(64, dtype=torch.int32, device=DEV)
+    res = torch.zeros(64 + n, dtype=torch.int32, device=DEV)
     ops.verify_stochastic(dev(target), d_draft, d_tokens, dev(r16), dev(off), dev(ids) if len(ids) else None, n, gt,
                           T, u24, ws, res)
     return res.cpu().numpy(), d_tokens.cpu().numpy(), d_draft.cpu().numpy()
@@ -356,7 +356,7 @@ def test_verify_greedy(ops):
         tokens = z[f"step{s}/tokens_pre"].copy()
         d_tokens = dev(tokens)
         ws = ops.verify_workspace(n, DEV)
-        res = torch.zeros(64, dtype=torch.int32, device=DEV)
+        res = torch.zeros(64 + n, dtype=torch.int32, device=DEV)
         ops.verify_greedy(dev(z[f"step{s}/target_logits"]), d_tokens, dev(off), dev(ids), n, gt, ws, res)
         want = O.verify_greedy(z[f"step{s}/target_logits"], tokens, succ, gt)
         r = res.cpu().numpy()
@@ -390,3 +390,25 @@ def test_rmsnorm_silu(ops):
     ops.silu_mul(gu, o)
     want = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
     assert (o.float() - want.float()).abs().max() < 4e-3
+
+
+def test_verify_greedy_deep_chain(ops):
+    """Accepted path longer than the 56-slot header: the full list follows the header."""
+    n, V, gt = 100, 1024, 10
+    succ = [[i + 1] for i in range(n - 1)] + [[]]
+    off, ids = csr(succ)
+    rng = np.random.RandomState(9)
+    tokens = rng.randint(3, V, size=gt + n + 4).astype(np.int64)
+    logits = (rng.randn(n, V)).astype(np.float16)
+    for t in range(n - 1):           # node t's target argmax == the token of its only child
+        logits[t, tokens[t + 1 + gt - 1]] = np.float16(30.0)
+    d_tokens = dev(tokens)
+    ws = ops.verify_workspace(n, DEV)
+    res = torch.zeros(64 + n, dtype=torch.int32, device=DEV)
+    ops.verify_greedy(dev(logits), d_tokens, dev(off), dev(ids), n, gt, ws, res)
+    o_tokens = tokens.copy()
+    want = O.verify_greedy(logits, o_tokens, succ, gt)
+    r = res.cpu().numpy()
+    assert want["n_tree"] == n - 1 and r[1] == n - 1 and r[0] == want["accept_len"]
+    assert list(r[64:64 + n - 1]) == want["slots"] and list(r[8:64]) == want["slots"][:56]
+    assert np.array_equal(d_tokens.cpu().numpy()[:want["accept_len"] + 1], o_tokens[:want["accept_len"] + 1])

@@ -85,7 +85,7 @@ if what in ("verify", "all"):
     toks = torch.randint(3, V, (M,), device=dev)
     r = torch.rand(M, device=dev).half()
     ws = ops.verify_workspace(n, dev)
-    rr = torch.zeros(64, dtype=torch.int32, device=dev)
+    rr = torch.zeros(64 + n, dtype=torch.int32, device=dev)
 
     def f():
         ops.verify_stochastic(tl, dl, toks, r, gd["child_off"], gd["child_ids"], n, 160, 0.6, 12345, ws, rr)
