@@ -33,6 +33,10 @@ MODELS = {
     "C": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="8x8-tree", mode="greedy", M=384),
     "D": dict(draft="princeton-nlp/Sheared-LLaMA-1.3B", target="meta-llama/Llama-2-13b-hf",
               growmap="A100-CNN-160m-13b-stochastic", mode="stochastic", M=384),
+    # 70B target sharded tensor-parallel over all launched ranks (replaces the reference's host offload);
+    # every rank runs the replicated draft + verifier, so N ranks serve ONE request stream ("strong")
+    "E": dict(draft="meta-llama/Llama-2-7b-hf", target="meta-llama/Llama-2-70b-hf", growmap="64x2-tree",
+              mode="stochastic", M=1024, tp=True),
 }
 
 
@@ -47,11 +51,17 @@ def build(cfg, device, pair, seed_d=1, seed_t=2):
     M = cfg["M"]
     if pair == "calibrated":
         from sequoia_amd.synthetic import calibrated_pair_specs
-        dspec, tspec = calibrated_pair_specs(cfg["draft"], cfg["target"], device)
+        tpw = int(os.environ.get("WORLD_SIZE", "1")) if cfg.get("tp") else 1
+        tpr = int(os.environ.get("RANK", "0")) if cfg.get("tp") else 0
+        dspec, tspec = calibrated_pair_specs(cfg["draft"], cfg["target"], device, tp_world=tpw, tp_rank=tpr)
     else:
         dspec, tspec = f"random:{cfg['draft']}:seed={seed_d}", f"random:{cfg['target']}:seed={seed_t}"
     draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
-    target = GraphInferenceEngineTG(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
+    if cfg.get("tp"):
+        from sequoia_amd.Engine.offload_engine import OffloadEngine
+        target = OffloadEngine(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
+    else:
+        target = GraphInferenceEngineTG(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
     gm = GrowMap.load(cfg["growmap"])
     return draft, target, gm
 
@@ -73,7 +83,8 @@ class Loop:
         if use_graphs:
             lens = sorted({lv.total for lv in g.levels} | {1})
             draft.initialize_cuda_graph(lens, tree_bitmask=gdev["bitmask"], n_tree=g.size)
-            target.initialize_cuda_graph([g.size], tree_bitmask=gdev["bitmask"], n_tree=g.size)
+            if hasattr(target, "initialize_cuda_graph"):
+                target.initialize_cuda_graph([g.size], tree_bitmask=gdev["bitmask"], n_tree=g.size)
         self.pi = 0
         self.tree = None
         self.cur_len = 0
@@ -126,7 +137,7 @@ def kernel_rooflines(cfg, loop, device):
     g, gdev = growmap_on_device(loop.grow_map, device)
     n, V, M = g.size, 32000, cfg["M"]
     dims = tgt.model.dims
-    H, Hkv, D, L = dims.num_attention_heads, dims.num_key_value_heads, dims.head_dim, dims.num_hidden_layers
+    H, Hkv, D, L = dims.local_heads, dims.local_kv_heads, dims.head_dim, dims.num_hidden_layers
     gt = 160
     kv_len = gt - 1 + n
     res = {}
@@ -287,7 +298,10 @@ def main():
         from sequoia_amd import gemm_tuning
         gemm_tuned = gemm_tuning.enable()
     draft, target, gm = build(cfg, device, args.pair)
-    prompts = load_prompts()[rank::world] if world > 1 else load_prompts()
+    tp_mode = bool(cfg.get("tp"))
+    prompts = load_prompts()[rank::world] if (world > 1 and not tp_mode) else load_prompts()
+    if tp_mode:
+        torch.manual_seed(17)          # identical noise on every rank: replicated decisions, no broadcast
     loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs)
 
     loop.run_steps(args.warmup)
@@ -299,8 +313,11 @@ def main():
     if world > 1:
         dist.barrier()
         t = torch.tensor([secs], device=device); dist.all_reduce(t, op=dist.ReduceOp.MAX); secs = float(t)
-        c = torch.tensor([float(new_tok), float(steps)], device=device); dist.all_reduce(c)
-        new_tok, steps_all = float(c[0]), float(c[1])
+        if tp_mode:                    # all ranks produced the SAME tokens: count them once
+            steps_all = steps
+        else:
+            c = torch.tensor([float(new_tok), float(steps)], device=device); dist.all_reduce(c)
+            new_tok, steps_all = float(c[0]), float(c[1])
     else:
         steps_all = steps
 
@@ -310,8 +327,18 @@ def main():
         dom = max(per_step, key=per_step.get)
         d = kr[dom]
         peak_hbm = 8000.0
+        traffic = None
+        if dom == "tree_attention_target" and args.config == "B":
+            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+            # over tools/kbench.py at this shape; gfx950 correction 2*FETCH + WRITE), profiles/r01_pmc_*.json
+            try:
+                with open(os.path.join(REPO, "profiles", "r01_pmc_tree_attention.json")) as f:
+                    pm = json.load(f)["kernels"]
+                traffic = pm["void tree_attention_kernel<128, true>(AttnParams)|grid=131072"]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         roof = dict(bound="hbm", kernel=dom, achieved=d["bytes"] / d["seconds"] / 1e9, peak=peak_hbm, unit="GB/s",
-                    frac=d["bytes"] / d["seconds"] / 1e9 / peak_hbm, traffic=None,
+                    frac=d["bytes"] / d["seconds"] / 1e9 / peak_hbm, traffic=traffic,
                     avg_launch_us=d["seconds"] * 1e6, algorithmic_bytes_per_launch=d["bytes"],
                     time_per_step_us=per_step[dom] * 1e6)
         kernels = {k: dict(avg_us=v["seconds"] * 1e6, gbps=v["bytes"] / v["seconds"] / 1e9,
@@ -325,12 +352,12 @@ def main():
                            sample=f"failed: {type(e).__name__}: {e}")
         line = dict(metric="accepted tokens/sec", value=new_tok / secs, unit="tokens/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=secs / args.steps * 1e3,
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
+                    higher_is_better=True, scaling="strong" if tp_mode else "weak", vs_baseline=None, dtype="f16", data="synthetic",
                     config=dict(workload=f"config {args.config}: {cfg['draft']} -> {cfg['target']} architectures "
                                          f"({args.pair} random-init weights), growmap {cfg['growmap']} "
                                          f"({gm.size}-node tree), T=0.6, top_p=1.0, M={cfg['M']}, 128-token c4_small "
                                          f"prompts, generate to 256",
-                                parallelism="replicas" if world > 1 else "single", graphs=not args.no_graphs,
+                                parallelism=(f"tp{world}" if tp_mode else ("replicas" if world > 1 else "single")), graphs=not args.no_graphs,
                                 gemm="torch TunableOp (hipBLASLt/rocBLAS solution picked per shape)" if gemm_tuned
                                 else "torch default"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs,

@@ -72,10 +72,21 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
     // tile of a head shares its XCD (pure speed hint: any placement is correct).
     const int n_tiles = (P.q_len + ATT_BM - 1) / ATT_BM;
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int head = xcd + 8 * (jj / n_tiles);
-    if (head >= P.n_heads) return;           // uniform per block
-    const int q0 = (jj % n_tiles) * ATT_BM;
-    const int kvh = head / (P.n_heads / P.h_kv);
+    const int grp = P.n_heads / P.h_kv;
+    int head, q0;
+    if (P.h_kv >= 8) {
+        // GQA with enough KV heads to fill the XCDs: all query heads of a KV head share its XCD
+        const int unit = grp * n_tiles;
+        const int kvh_x = xcd + 8 * (jj / unit), within = jj % unit;
+        if (kvh_x >= P.h_kv) return;         // uniform per block
+        head = kvh_x * grp + within / n_tiles;
+        q0 = (within % n_tiles) * ATT_BM;
+    } else {
+        head = xcd + 8 * (jj / n_tiles);
+        if (head >= P.n_heads) return;       // uniform per block
+        q0 = (jj % n_tiles) * ATT_BM;
+    }
+    const int kvh = head / grp;
     const half_t* kbase = P.k + (size_t)kvh * P.m * D;
     const half_t* vbase = P.v + (size_t)kvh * P.m * D;
 
@@ -330,7 +341,8 @@ extern "C" int sq_tree_attention_f16(const void* q, const void* k_layer, const v
     }
     if (q_len == 0) return SQ_OK;
     const int n_tiles = (q_len + ATT_BM - 1) / ATT_BM;
-    dim3 grid(8 * ((n_heads + 7) / 8) * n_tiles), block(ATT_THREADS);
+    const int slots = h_kv >= 8 ? 8 * ((h_kv + 7) / 8) * (n_heads / h_kv) : 8 * ((n_heads + 7) / 8);
+    dim3 grid(slots * n_tiles), block(ATT_THREADS);
     static const bool no_tr = getenv("SQ_ATTN_NO_TR") != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (d == 128) {

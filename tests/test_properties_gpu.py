@@ -1,0 +1,144 @@
+"""Size-independent properties of the native path on the MI355X.
+
+* losslessness of the Sequoia verifier: over fresh noise, the first token emitted by
+  (sample children without replacement from q) -> (residual accept/reject) -> (bonus from the
+  residual) is distributed exactly like the target distribution p, whatever q is
+  (the theorem the reference's algorithm rests on; Tree/SpecTree.py:136-157);
+* draft == target (same weights): every level's first child is accepted, so a step commits the
+  full tree depth (stochastic up to the one-ulp p/q difference between the two call paths);
+* samplers: outputs are distinct, ordered by key, identical under row permutation;
+* KV: scatter -> compact is the gather of the accepted rows, at the full 7B / M=384 cache size.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sequoia_amd.ops import HipOps
+    return HipOps()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_verifier_is_lossless_in_distribution(ops):
+    """chi-square of the first emitted token against p, 24k trials, V = 16, root with 3 children."""
+    V, n, gt, T = 16, 4, 5, 1.0
+    succ_off = np.array([0, 3, 3, 3, 3], dtype=np.int32)
+    succ_ids = np.array([1, 2, 3], dtype=np.int32)
+    rng = np.random.RandomState(1)
+    tl = np.zeros((n, V), np.float16); dl = np.zeros((n, V), np.float16)
+    tl[0] = (rng.randn(V) * 1.2).astype(np.float16)
+    dl[0] = (tl[0].astype(np.float32) * 0.3 + rng.randn(V) * 1.0).astype(np.float16)   # a poor draft
+    for t in range(1, n):
+        tl[t] = (rng.randn(V)).astype(np.float16)
+    from oracle import ops_np as O
+    p = O.scaled_softmax_f16(tl[0], T).astype(np.float64)
+    p /= p.sum()
+    trials = 24000
+    g = torch.Generator().manual_seed(5)
+    d_tl, d_off, d_ids = dev(tl), dev(succ_off), dev(succ_ids)
+    ws = ops.verify_workspace(n, DEV)
+    res = torch.zeros(64 + n, dtype=torch.int32, device=DEV)
+    tokens = torch.zeros(16, dtype=torch.int64, device=DEV)
+    branch, out_off = dev(np.array([3], np.int32)), dev(np.array([0], np.int32))
+    row0 = dev(np.array([0], np.int32))
+    # fp16 uniforms on torch's grid k/2048; r and rand fresh per trial
+    rand_all = (torch.randint(0, 2048, (trials, V), generator=g).float() / 2048).half().to(DEV)
+    r_all = (torch.randint(0, 2048, (trials, 16), generator=g).float() / 2048).half().to(DEV)
+    u_all = torch.randint(0, 1 << 24, (trials,), generator=g).tolist()
+    first = torch.zeros(trials, dtype=torch.int64, device=DEV)
+    d_dl0 = dev(dl)
+    for i in range(trials):
+        d_dl = d_dl0.clone()                         # the verifier writes -65504 into rejected entries
+        ops.sample_wor(d_dl, rand_all[i:i + 1], row0, 3, T, tokens[gt:], branch=branch, out_off=out_off)
+        ops.verify_stochastic(d_tl, d_dl, tokens, r_all[i], d_off, d_ids, n, gt, T, u_all[i], ws, res)
+        first[i] = tokens[gt]                        # first accepted child, or the bonus token
+    counts = np.bincount(first.cpu().numpy(), minlength=V).astype(np.float64)
+    exp = p * trials
+    keep = exp > 5
+    chi2 = (((counts - exp) ** 2) / exp)[keep].sum()
+    dof = int(keep.sum()) - 1
+    # 99.9% quantile of chi2(dof<=15) is < 38; a biased verifier (e.g. >= instead of >, or a
+    # residual without renormalisation) lands in the hundreds
+    assert chi2 < 45, (chi2, dof, counts, exp)
+
+
+@pytest.mark.parametrize("mode", ["stochastic", "greedy"])
+def test_identical_draft_and_target_commit_full_depth(mode):
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
+    from sequoia_amd.growmap import GrowMap
+    from sequoia_amd.Tree.GreedyTree import GreedyTree
+    from sequoia_amd.Tree.SpecTree import SpecTree
+    M = 384
+    spec = "random:JackFram/llama-68m:seed=4:gain=40"          # peaked logits: decisions far from ties
+    draft = GraphInferenceEngine(max_length=M, model_name_or_path=spec, dtype=torch.float16, device=DEV)
+    target = GraphInferenceEngineTG(max_length=M, model_name_or_path=spec, dtype=torch.float16, device=DEV)
+    gname = "A100-CNN-68m-7b-stochastic" if mode == "stochastic" else "8x8-tree"
+    gm = GrowMap.load(gname)
+    depth = gm.draft_step - 1
+    cls = SpecTree if mode == "stochastic" else GreedyTree
+    torch.manual_seed(3)
+    tree = cls(prefix=torch.randint(3, 32000, (128,)), device=DEV, temperature=0.6, top_p=1.0, draft_kv_len=0,
+               target_kv_len=0, draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
+               grow_map=gm.to_reference_dict(), attn_mask=None, sequence=None, new_tokens_buffer=None,
+               parents_buffer=None, position_ids=torch.zeros(M, dtype=torch.long, device=DEV), residual_graph=None,
+               sampling_callables=None, sample_gather_indices=None)
+    cur, accepted = 128, []
+    for _ in range(12):
+        tree.construct_grow_map()
+        valid, a, _, term = tree.verify()
+        accepted.append(valid.shape[0] - cur - 1)       # accepted tree nodes (bonus excluded)
+        cur = valid.shape[0]
+        if term or cur + gm.size >= M:
+            break
+    # the first child of every level passes p > r*q when p == q (r < 1): full depth, every step
+    assert np.mean(np.array(accepted) == depth) >= 0.75, accepted
+    assert max(accepted) == depth
+
+
+def test_sampler_invariants_full_vocab(ops):
+    V, R, k = 32000, 34, 6
+    g = torch.Generator(device=DEV).manual_seed(11)
+    logits = (torch.randn(R, V, generator=g, device=DEV) * 4).half()
+    rand = (torch.randint(0, 2048, (R, V), generator=g, device=DEV).float() / 2048).half()
+    out = torch.zeros(R * k, dtype=torch.int64, device=DEV)
+    ops.sample_wor(logits, rand, None, k, 0.6, out)
+    o = out.view(R, k)
+    assert all(len(set(row.tolist())) == k for row in o)                 # without replacement
+    assert int(o.min()) >= 0 and int(o.max()) < V
+    perm = torch.randperm(R, device=DEV).int()
+    out2 = torch.zeros(R * k, dtype=torch.int64, device=DEV)
+    ops.sample_wor(logits, rand, perm, k, 0.6, out2)                     # row gather == permuting the result
+    assert torch.equal(out2.view(R, k), o[perm.long()])
+    out3 = torch.zeros(R * k, dtype=torch.int64, device=DEV)
+    ops.topk(logits, None, k, out3)
+    vals = torch.gather(logits, 1, out3.view(R, k))
+    assert torch.equal(vals, torch.sort(vals, dim=1, descending=True).values)        # sorted by key
+    assert torch.equal(vals, torch.topk(logits, k, dim=1).values)                    # == torch's values
+
+
+def test_kv_round_trip_full_size(ops):
+    """7B cache [32,1,32,384,128] x2 = 192 MiB: scatter rows, compact an accepted path, compare with
+    an index_select of the original rows; untouched rows keep their bytes."""
+    L, H, M, D = 32, 32, 384, 128
+    g = torch.Generator(device=DEV).manual_seed(2)
+    k = torch.randn(L, 1, H, M, D, generator=g, device=DEV).half()
+    v = torch.randn(L, 1, H, M, D, generator=g, device=DEV).half()
+    k0, v0 = k.clone(), v.clone()
+    gt, slots = 200, [203, 230, 231, 290, 327]
+    ds = torch.tensor(slots, dtype=torch.int32, device=DEV)
+    ops.kv_compact(k, v, ds, None, len(slots), gt, 0)
+    idx = torch.tensor(slots, device=DEV)
+    assert torch.equal(k[..., gt:gt + 5, :], k0[..., idx, :]) and torch.equal(v[..., gt:gt + 5, :], v0[..., idx, :])
+    assert torch.equal(k[..., :gt, :], k0[..., :gt, :]) and torch.equal(k[..., gt + 5:, :], k0[..., gt + 5:, :])
+    # idempotence: compacting the already-compacted prefix is the identity
+    k1 = k.clone()
+    ops.kv_compact(k, v, torch.arange(gt, gt + 5, dtype=torch.int32, device=DEV), None, 5, gt, 0)
+    assert torch.equal(k, k1)
