@@ -16,8 +16,9 @@
 //         -> lane (q = lane&15, g = lane>>4) holds keys {16t + 4g + r}: exactly the A-operand
 //            layout the P V MFMA wants (k-slot 8g + j <-> key 16(j>>2) + 4g + (j&3)), so P never
 //            leaves registers.
-//   O  += P V     (B = V through a wave-private LDS tile, read back transposed with
-//                  ds_read_b64_tr_b16; the same key permutation is applied by construction).
+//   O^T += V^T P^T (A = V^T through a wave-private LDS tile read back transposed with
+//                  ds_read_b64_tr_b16, B = P^T = the registers S^T left behind): the accumulator
+//                  column is again the lane's own query, so the online-softmax rescale is lane-local.
 #include "common.h"
 #include <stdlib.h>
 
@@ -44,7 +45,36 @@ struct AttnParams {
     const int32_t* ctx;     // optional device override of {q_slot0, gt, kv_len} (hipGraph replays)
 };
 
-template <int D, bool TR>
+// max / sum over the four 16-lane groups holding the same query (lanes l, l^16, l^32, l^48) with the
+// gfx950 VALU lane swaps (v_permlane16_swap / v_permlane32_swap) instead of LDS-routed ds_bpermute
+// (inline asm: with ROCm 7.2's clang the __builtin_amdgcn_permlane*_swap builtins return the first
+// result twice; the s_nop's are the VALU-write -> permlane-read wait states hipcc would insert.)
+__device__ __forceinline__ void lane_swap16(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_swap32(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float group4_max(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    lane_swap16(a, b);                   // a = rows [0,0,2,2], b = rows [1,1,3,3]
+    v = fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+    a = __builtin_bit_cast(unsigned, v); b = a;
+    lane_swap32(a, b);                   // a = lower half twice, b = upper half twice
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+__device__ __forceinline__ float group4_sum(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    lane_swap16(a, b);
+    v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    a = __builtin_bit_cast(unsigned, v); b = a;
+    lane_swap32(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
+// MASK: 0 = dense additive mask, 1 = tree mask with the bitmask row in two registers (n <= 128),
+// 2 = tree mask with the bitmask rows staged in LDS (n <= 512).
+template <int D, int MASK>
 __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams P) {
     if (P.ctx) {   // uniform: step-dependent scalars live in device memory so the launch is graph-replayable
         P.q_slot0 = P.ctx[0]; P.gt = P.ctx[1]; P.kv_len = P.ctx[2];
@@ -55,7 +85,8 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
     constexpr int NT = D / 16;           // 16-wide output column tiles
     constexpr int VSTRIDE = D + 8;       // halves; +16 B keeps ds_write_b128 aligned and de-phases banks
     constexpr int V_TILE = 2 * ATT_BK * VSTRIDE;                // halves per wave: V tile then K tile
-    constexpr int O_TILE = ATT_BM * D;                          // floats per wave
+    constexpr int OSTR = D + 4;                                 // padded row of the merge tile (floats): 16-byte stores from 8 lanes hit 8 distinct bank quads
+    constexpr int O_TILE = ATT_BM * OSTR;                       // floats per wave
     // LDS: V staging (per wave) is reused for the cross-wave merge of O.
     constexpr int LDS_BYTES_V = ATT_WAVES * V_TILE * 2;
     constexpr int LDS_BYTES_O = ATT_WAVES * O_TILE * 4;
@@ -97,7 +128,19 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
     const int slot = P.q_slot0 + qi_c;
     const int tnode = slot - (P.gt - 1);
 
-    if (P.mask_mode == 1) {
+    // this lane's ancestor-bitmask row: trees up to 128 nodes (2 words) live in two registers, larger
+    // trees are staged in LDS
+    uint64_t bm0 = 0ull, bm1 = 0ull;
+    if constexpr (MASK == 1) {
+        if (tnode >= 1 && tnode < P.n_tree) {
+            bm0 = P.bitmask[(size_t)tnode * P.words];
+            if (P.words == 2) bm1 = P.bitmask[(size_t)tnode * P.words + 1];
+        }
+    }
+    // branch-free visibility test: per-lane constants hoisted out of the key loop
+    const bool causal_row = slot < P.gt;                 // committed-text query: plain causal row
+    const bool tree_ok = tnode < P.n_tree;
+    if constexpr (MASK == 2) {
         // stage the ancestor-bitmask rows of the 16 queries
         for (int i = tid; i < ATT_BM * P.words; i += ATT_THREADS) {
             const int r = i / P.words, w = i - r * P.words;
@@ -184,27 +227,28 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
             for (int r = 0; r < 4; ++r) {
                 const int key = key0 + t * 16 + g * 4 + r;
                 float x = s_acc[t][r] * P.scale_log2e;
-                bool vis = key < P.kv_len;
-                if (P.mask_mode == 1) {
-                    if (vis) {
-                        if (slot < P.gt) vis = key <= slot;
-                        else if (key >= P.gt) {
-                            const int j = key - (P.gt - 1);
-                            vis = (tnode < P.n_tree) && (j < P.n_tree) &&
-                                  ((lds_bm[qc * P.words + (j >> 6)] >> (j & 63)) & 1ull);
-                        }
-                    }
-                    if (!vis) x = -INFINITY;
+                const bool in_len = key < P.kv_len;
+                if constexpr (MASK == 0) {
+                    const int kc = in_len ? key : 0;
+                    const float mk = (float)P.dense[(size_t)qi_c * P.mask_stride + kc] * 1.4426950408889634f;
+                    x = in_len ? x + mk : -INFINITY;
                 } else {
-                    if (vis) x += (float)P.dense[(size_t)qi_c * P.mask_stride + key] * 1.4426950408889634f;
-                    else x = -INFINITY;
+                    // tree rule without branches: every lane evaluates both the causal and the tree
+                    // predicate and selects (divergent if/else chains cost ~40 cycles per branch here)
+                    const int j = key - (P.gt - 1);
+                    uint64_t wv;
+                    if constexpr (MASK == 1) wv = (j & 64) ? bm1 : bm0;
+                    else wv = lds_bm[qc * P.words + (((unsigned)j >> 6) < (unsigned)P.words ? (j >> 6) : 0)];
+                    const bool bit = (wv >> (j & 63)) & 1ull;
+                    const bool vis_tree = (key < P.gt) | (tree_ok & ((unsigned)j < (unsigned)P.n_tree) & bit);
+                    const bool vis = in_len & (causal_row ? (key <= slot) : vis_tree);
+                    x = vis ? x : -INFINITY;
                 }
                 sv[t * 4 + r] = x;
                 cmax = fmaxf(cmax, x);
             }
         }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        cmax = group4_max(cmax);
         const float m_new = fmaxf(m_run, cmax);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;      // fully masked so far
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // exp2(-inf) = 0 on the first chunk
@@ -218,11 +262,8 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
-        // O rows are q = 4g + r: fetch their alphas from the lanes that own those queries
-        float a4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a4[r] = __shfl(alpha, g * 4 + r, 64);
-        // ---- O += P V ---------------------------------------------------------------------------
+        // ---- O^T += V^T P^T: A = V^T fragment (rows = d), B = P^T (n = this lane's query), so the
+        //      accumulator column is the lane's own query and the rescale by alpha is lane-local ------
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -233,21 +274,14 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
             const half_t* a0 = my_v + (0 * 16 + g * 4 + (qc >> 2)) * VSTRIDE + nt * 16 + (qc & 3) * 4;
             const half_t* a1 = my_v + (1 * 16 + g * 4 + (qc >> 2)) * VSTRIDE + nt * 16 + (qc & 3) * 4;
             half8 vf;
-            if constexpr (TR) {
-                const fp16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
-                const fp16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a1);
+            const fp16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
+            const fp16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { vf[j] = (half_t)b0[j]; vf[4 + j] = (half_t)b1[j]; }
-            } else {
-                // plain 2-byte gathers (debug / fallback variant, SQ_ATTN_NO_TR=1)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    vf[j] = my_v[((j >> 2) * 16 + g * 4 + (j & 3)) * VSTRIDE + nt * 16 + qc];
-            }
+            for (int j = 0; j < 4; ++j) { vf[j] = (half_t)b0[j]; vf[4 + j] = (half_t)b1[j]; }
             floatx4 o = o_acc[nt];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] *= a4[r];
-            o_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) o[r] *= alpha;
+            o_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o, 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
         if (has_next) {
@@ -257,15 +291,13 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
     }
 
     // ---- merge the waves ---------------------------------------------------------------------
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    l_run = group4_sum(l_run);
     __syncthreads();                       // everyone is done with the V staging area
     if (g == 0) { lds_ml[(wave * ATT_BM + qc) * 2] = m_run; lds_ml[(wave * ATT_BM + qc) * 2 + 1] = l_run; }
+    // o_acc[nt][r] = O[q = qc][d = 16 nt + 4 g + r]: four consecutive d per lane -> one 16-byte LDS store
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            lds_o[(wave * ATT_BM + g * 4 + r) * D + nt * 16 + qc] = o_acc[nt][r];
+        *(floatx4*)(lds_o + (wave * ATT_BM + qc) * OSTR + nt * 16 + g * 4) = o_acc[nt];
     __syncthreads();
     {
         constexpr int EPT_O = ATT_BM * D / ATT_THREADS;       // 4 (D=128) or 2 (D=64)
@@ -292,7 +324,7 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
             for (int e = 0; e < EPT_O; ++e) {
                 float acc = 0.f;
 #pragma unroll
-                for (int w = 0; w < ATT_WAVES; ++w) acc += lds_o[(w * ATT_BM + row) * D + col + e] * wgt[w];
+                for (int w = 0; w < ATT_WAVES; ++w) acc += lds_o[(w * ATT_BM + row) * OSTR + col + e] * wgt[w];
                 res[e] = acc * inv;
             }
             if constexpr (EPT_O == 8) {
@@ -343,14 +375,11 @@ extern "C" int sq_tree_attention_f16(const void* q, const void* k_layer, const v
     const int n_tiles = (q_len + ATT_BM - 1) / ATT_BM;
     const int slots = h_kv >= 8 ? 8 * ((h_kv + 7) / 8) * (n_heads / h_kv) : 8 * ((n_heads + 7) / 8);
     dim3 grid(slots * n_tiles), block(ATT_THREADS);
-    static const bool no_tr = getenv("SQ_ATTN_NO_TR") != nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (d == 128) {
-        if (no_tr) hipLaunchKernelGGL((tree_attention_kernel<128, false>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((tree_attention_kernel<128, true>), grid, block, 0, st, P);
-    } else {
-        if (no_tr) hipLaunchKernelGGL((tree_attention_kernel<64, false>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((tree_attention_kernel<64, true>), grid, block, 0, st, P);
-    }
+    const int mk = mask_mode == 0 ? 0 : (P.words <= 2 ? 1 : 2);
+#define SQ_ATT(DD, MM) hipLaunchKernelGGL((tree_attention_kernel<DD, MM>), grid, block, 0, st, P)
+    if (d == 128) { if (mk == 0) SQ_ATT(128, 0); else if (mk == 1) SQ_ATT(128, 1); else SQ_ATT(128, 2); }
+    else          { if (mk == 0) SQ_ATT(64, 0);  else if (mk == 1) SQ_ATT(64, 1);  else SQ_ATT(64, 2); }
+#undef SQ_ATT
     return sq_check_launch();
 }
