@@ -174,6 +174,13 @@ int sq_verify_stochastic_f16(const void* target_logits, void* draft_logits,
                              uint32_t bonus_u24, void* workspace, int32_t* d_result,
                              void* stream);
 
+/* utils.get_sampling_logits (utils.py:65-77), applied by SpecTree.verify to the target logits
+ * before the softmax (Tree/SpecTree.py:196): in place, rows [n_rows][ld]; a token is set to -inf
+ * iff the softmax(logits/T) mass of the tokens ranked before it (descending logit, ties by token
+ * id) exceeds top_p (compared in fp16 like the reference's fp16 cumsum).  Identity for top_p >= 1. */
+int sq_top_p_filter_f16(void* logits, int64_t ld, int n_rows, int vocab, float top_p,
+                        float temperature, void* stream);
+
 /* GreedyTree.verify after the target forward (Tree/GreedyTree.py:186-207): argmax per node,
  * walk by token equality, bonus = target argmax at the last accepted node.  tokens are only
  * compacted / bonus written when not terminal... the compaction tokens[:a] happens always

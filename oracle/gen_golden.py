@@ -259,6 +259,8 @@ def gen_rows_fullvocab(R, out_dir):
         p = torch.softmax(logits[0] / 0.6, dim=-1)
         q = torch.softmax(logits[1] / 0.6, dim=-1)
         arrays[f"wor{i}/residual"] = RU.get_residual(p, q).numpy()
+        arrays[f"wor{i}/topp09"] = RU.get_sampling_logits(logits.clone(), 0.9, 0.6).numpy()
+        arrays[f"wor{i}/topp05"] = RU.get_sampling_logits(logits.clone(), 0.5, 0.6).numpy()
     path = os.path.join(out_dir, "rows_v32000.npz")
     np.savez_compressed(path, **arrays)
     print("rows ->", path, f"({os.path.getsize(path) / 1e6:.2f} MB)")

@@ -106,6 +106,11 @@ class OracleOps:
         self._fill(result, res)
         return result
 
+    def top_p_filter(self, logits, top_p, temperature):
+        if top_p < 1.0:
+            logits.copy_(torch.from_numpy(O.top_p_filter(_np(logits), top_p, temperature)))
+        return logits
+
     def verify_greedy(self, target_logits, tokens, child_off, child_ids, n_tree, gt, workspace, result):
         succ = _succ_from_csr(child_off, child_ids, n_tree)
         self._fill(result, O.verify_greedy(_np(target_logits), _np(tokens), succ, gt))

@@ -338,6 +338,34 @@ def verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, 
 
 
 # --------------------------------------------------------------------------------------------
+# a6. nucleus (top-p) filter on the target logits (utils.py:65-77, called at Tree/SpecTree.py:196)
+# --------------------------------------------------------------------------------------------
+def top_p_filter(logits16, top_p, temperature):
+    """Rows [n, V] fp16 -> copy with the removed tokens set to -inf.
+
+    Reference: sort descending, cumulative_probs = cumsum(softmax(sorted/T)) (fp16), token at
+    sorted rank k is removed iff cumulative_probs[k-1] > top_p (the comparison runs in fp16: the
+    python scalar is cast to the tensor dtype).  Restated with the cumulative mass summed exactly on
+    the 2^-24 grid and then rounded to fp16 (torch accumulates in fp32 and rounds: identical except
+    on rounding boundaries), ties between equal logits ordered by token id (torch.sort leaves the
+    order of equal keys unspecified)."""
+    out = logits16.copy()
+    th16 = np.float16(top_p)
+    for r in range(logits16.shape[0]):
+        p16 = scaled_softmax_f16(logits16[r], temperature)
+        xf = f(logits16[r]).copy()
+        xf[np.isnan(xf)] = np.inf
+        order = np.lexsort((np.arange(xf.shape[0]), -xf))
+        w = _grid_int(np.where(np.isnan(p16), np.float16(0), p16))[order]
+        before = np.concatenate([[0], np.cumsum(w)[:-1]])                 # mass ranked strictly before
+        c16 = (before.astype(np.float64) / _TWO24).astype(np.float16)
+        remove = c16 > th16
+        remove[0] = False
+        out[r, order[remove]] = np.float16(-np.inf)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # a8. greedy verification (Tree/GreedyTree.py:131-146,186-209)
 # --------------------------------------------------------------------------------------------
 def argmax_first(x16):

@@ -142,12 +142,20 @@ class GraphInferenceEngine:
                                      device=device, **model_kw)
         self.callables = {}        # dense-mask graphs, keyed by decoding length (reference contract)
         self.tree_callables = {}   # implicit-mask graphs, keyed by (decoding length, id(bitmask))
+        self.requested_graph_lengths = set()   # lengths the harness asked for (tests/testbed.py:266-268)
         self.mempool = None
 
     @torch.inference_mode()
-    def initialize_cuda_graph(self, decoding_seqlens: List[int], n_warmups=3, tree_bitmask=None, n_tree: int = 1):
-        """Capture one graph per decoding length.  With `tree_bitmask` (the growmap's device
-        bitmask) the graphs use the implicit tree mask; without, the dense-mask signature."""
+    def initialize_cuda_graph(self, decoding_seqlens: List[int], n_warmups=3, tree_bitmask=None, n_tree: int = 1,
+                              clear_kv: bool = True):
+        """Capture one graph per decoding length (reference: Engine/Engine.py:181-195).
+
+        Without `tree_bitmask` (the reference's call) the lengths are recorded and the graphs for
+        the implicit-mask path are captured the first time a tree with a concrete growmap uses
+        this engine (NativeTree.__init__, outside any timed region).  Callers that drive
+        graph_inference() with a dense attn_mask tensor run eagerly unless they capture dense graphs
+        explicitly with capture_dense_graphs().  With `tree_bitmask` (the growmap's device bitmask)
+        the implicit-mask graphs are captured now."""
         gc.collect()
         if self.mempool is None:
             self.mempool = torch.cuda.graphs.graph_pool_handle()
@@ -155,14 +163,37 @@ class GraphInferenceEngine:
             if q_len == 0:
                 continue
             if tree_bitmask is None:
-                if q_len not in self.callables:
-                    self.callables[q_len] = _GraphRunner(self.engine, q_len, self.mempool, n_warmups, "dense")
+                self.requested_graph_lengths.add(int(q_len))
             else:
                 key = (q_len, tree_bitmask.data_ptr())
                 if key not in self.tree_callables:
                     self.tree_callables[key] = _GraphRunner(self.engine, q_len, self.mempool, n_warmups, "tree",
                                                             n_tree=n_tree, bitmask=tree_bitmask)
+        if clear_kv:
+            self.engine.clear_kv()
+
+    @torch.inference_mode()
+    def capture_dense_graphs(self, decoding_seqlens: List[int], n_warmups=3):
+        """The reference's capture_graph behaviour (static [q, M] mask buffer per length).  Only legal
+        while the KV cache is empty: the capture runs the forward on scratch slots."""
+        if self.engine.kv_cache.kv_offset != 0:
+            raise RuntimeError("capture_dense_graphs() must run before any token is cached")
+        if self.mempool is None:
+            self.mempool = torch.cuda.graphs.graph_pool_handle()
+        for q_len in decoding_seqlens:
+            if q_len and q_len not in self.callables:
+                self.callables[q_len] = _GraphRunner(self.engine, q_len, self.mempool, n_warmups, "dense")
         self.engine.clear_kv()
+
+    def ensure_tree_graphs(self, tree_bitmask, n_tree: int, extra_lengths=()):
+        """Capture implicit-mask graphs for every requested length not yet captured for this growmap."""
+        want = [q for q in sorted(self.requested_graph_lengths | set(extra_lengths))
+                if (q, tree_bitmask.data_ptr()) not in self.tree_callables]
+        if want:
+            kv = self.engine.kv_cache
+            saved = (kv.kv_offset, kv.dirty_end)
+            self.initialize_cuda_graph(want, tree_bitmask=tree_bitmask, n_tree=n_tree, clear_kv=False)
+            kv.kv_offset, kv.dirty_end = saved
 
     @torch.inference_mode()
     def graph_inference(self, input_ids: torch.LongTensor, storage_ids: torch.LongTensor,

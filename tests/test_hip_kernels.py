@@ -412,3 +412,26 @@ def test_verify_greedy_deep_chain(ops):
     assert want["n_tree"] == n - 1 and r[1] == n - 1 and r[0] == want["accept_len"]
     assert list(r[64:64 + n - 1]) == want["slots"] and list(r[8:64]) == want["slots"][:56]
     assert np.array_equal(d_tokens.cpu().numpy()[:want["accept_len"] + 1], o_tokens[:want["accept_len"] + 1])
+
+
+@pytest.mark.parametrize("V,gain,top_p", [(32000, 3.0, 0.9), (32000, 1.0, 0.5), (32000, 8.0, 0.9), (1024, 2.0, 0.3)])
+def test_top_p_filter(ops, V, gain, top_p):
+    rng = np.random.RandomState(int(V * top_p))
+    logits = (rng.randn(6, V) * gain).astype(np.float16)
+    logits[1, :64] = np.float16(2.5)            # a big exact tie group
+    want = O.top_p_filter(logits, top_p, 0.6)
+    d = dev(logits)
+    ops.top_p_filter(d, top_p, 0.6)
+    got = d.cpu().numpy()
+    # exp() last-ulp differences can move the cut by a token; otherwise bit-identical
+    diff = (np.isinf(got) != np.isinf(want)).sum(axis=1)
+    assert diff.max() <= 2, diff
+    same = np.isinf(got) == np.isinf(want)
+    assert np.array_equal(got[same], want[same])
+    # reference outputs on the golden rows
+    if V == 32000 and top_p == 0.9:
+        z = np.load(f"{GOLDEN}/rows_v32000.npz")
+        for i in range(4):
+            d = dev(z[f"wor{i}/logits"])
+            ops.top_p_filter(d, 0.9, 0.6)
+            assert (np.isinf(d.cpu().numpy()) != np.isinf(z[f"wor{i}/topp09"])).sum(axis=1).max() <= 6

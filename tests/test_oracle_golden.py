@@ -154,3 +154,20 @@ def test_inverse_cdf_is_exact_and_distribution_correct():
     assert frac[1] == 0
     assert np.allclose(frac, [0.25, 0, 0.5, 0.25], atol=1e-3)
     assert O.inverse_cdf(p, 0) == 0 and O.inverse_cdf(p, (1 << 24) - 1) == 3
+
+
+def test_top_p_filter_matches_reference():
+    """utils.get_sampling_logits (utils.py:65-77) on V = 32000 rows: the set of removed tokens equals
+    the reference's except inside exact ties at the cut (torch.sort's tie order) / fp32-vs-exact
+    accumulation on a rounding boundary: at most a handful of tokens out of 32000."""
+    z = np.load(f"{GOLDEN}/rows_v32000.npz")
+    for i in range(4):
+        for tp, key in ((0.9, "topp09"), (0.5, "topp05")):
+            got = O.top_p_filter(z[f"wor{i}/logits"], tp, 0.6)
+            want = z[f"wor{i}/{key}"]
+            kept_equal = np.isinf(got) == np.isinf(want)
+            assert (~kept_equal).sum(axis=1).max() <= 6, (i, tp)
+            assert np.array_equal(got[kept_equal & ~np.isinf(got)], want[kept_equal & ~np.isinf(want)])
+            # the kept mass straddles top_p like the reference's
+            p = O.scaled_softmax_f16(z[f"wor{i}/logits"], 0.6).astype(np.float64)
+            assert (np.where(np.isinf(got), 0, p).sum(1) >= min(tp, p.max(1).min()) - 2e-3).all()
