@@ -51,19 +51,17 @@ class LayerWeights:
     w_down: torch.Tensor           # [hidden, I]
 
 
-def attention_block(h, lw: LayerWeights, layer_idx: int, dims, kv_cache, cos, sin, position_ids, storage_ids,
-                    dense_mask, tree: TreeContext | None, reduce_fn=None):
-    """h: [q, hidden] normalised input.  Returns the o_proj output [q, hidden].
-
-    Replaces LlamaAttention_FI/TG.forward (Engine/Llama_modules.py:87-140, 182-258)."""
+def attention_core(qkv, layer_idx: int, dims, kv_cache, cos, sin, position_ids, storage_ids, dense_mask,
+                   tree: TreeContext | None):
+    """qkv: [q, (H + 2 H_kv) D] packed projections.  RoPE + KV slot write + tree-batched attention;
+    returns the attention output [q, H D] (the o_proj input)."""
     ops = get_ops()
-    q_len = h.shape[0]
+    q_len = qkv.shape[0]
     n_heads, h_kv, d = dims.local_heads, dims.local_kv_heads, dims.head_dim
-    qkv = F.linear(h, lw.wqkv)                                         # hipBLASLt
-    q_rot = torch.empty((n_heads, q_len, d), dtype=h.dtype, device=h.device)
+    q_rot = torch.empty((n_heads, q_len, d), dtype=qkv.dtype, device=qkv.device)
     k_layer, v_layer = kv_cache.k_cache[layer_idx, 0], kv_cache.v_cache[layer_idx, 0]
     ops.rope_kv_write(qkv, q_rot, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d)
-    attn = torch.empty((q_len, n_heads * d), dtype=h.dtype, device=h.device)
+    attn = torch.empty((q_len, n_heads * d), dtype=qkv.dtype, device=qkv.device)
     scale = 1.0 / math.sqrt(d)
     if tree is not None:
         ops.tree_attention(q_rot, k_layer, v_layer, attn, tree.kv_len, scale, q_slot0=tree.q_slot0, gt=tree.gt,
@@ -75,6 +73,16 @@ def attention_block(h, lw: LayerWeights, layer_idx: int, dims, kv_cache, cos, si
         if kv_len > kv_cache.max_length:
             raise ValueError(f"Attention mask should cover at most {kv_cache.max_length} key slots, got {kv_len}")
         ops.tree_attention(q_rot, k_layer, v_layer, attn, kv_len, scale, dense_mask=dense_mask)
+    return attn
+
+
+def attention_block(h, lw: LayerWeights, layer_idx: int, dims, kv_cache, cos, sin, position_ids, storage_ids,
+                    dense_mask, tree: TreeContext | None, reduce_fn=None):
+    """h: [q, hidden] normalised input.  Returns the o_proj output [q, hidden].
+
+    Replaces LlamaAttention_FI/TG.forward (Engine/Llama_modules.py:87-140, 182-258)."""
+    qkv = F.linear(h, lw.wqkv)                                         # hipBLASLt
+    attn = attention_core(qkv, layer_idx, dims, kv_cache, cos, sin, position_ids, storage_ids, dense_mask, tree)
     out = F.linear(attn, lw.wo)
     if reduce_fn is not None:
         out = reduce_fn(out)                                           # TP: row-parallel all-reduce

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "sq_verify_greedy_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sq_rmsnorm_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_silu_mul_f16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sq_linear_skinny_f16": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_add_rmsnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 

@@ -105,3 +105,33 @@ def test_dense_mask_signature_matches_tree_context():
     target.clear_kv()
     with pytest.raises(ValueError):
         target.inference(input_ids=ids, storage_ids=sid, position_ids=pos, attn_mask=mask[None, None, :, :-1])
+
+
+def test_skinny_draft_forward_matches_general_path():
+    """68m draft architecture: the fused skinny forward (q <= 64) and the hipBLASLt + glue forward give
+    the same logits up to accumulation order (few fp16 ulps) and the same KV cache rows."""
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine
+    from sequoia_amd.Engine.Llama_modules import TreeContext
+    from sequoia_amd.growmap import GrowMap
+    M = 384
+    eng = GraphInferenceEngine(max_length=M, model_name_or_path="random:JackFram/llama-68m:seed=5:gain=20",
+                               dtype=torch.float16, device=DEV)
+    g = GrowMap.load("A100-CNN-68m-7b-stochastic")
+    bm = g.device_tensors(DEV)["bitmask"]
+    torch.manual_seed(0)
+    ids = torch.randint(3, 32000, (1, 160), device=DEV)
+    outs, caches = [], []
+    for use in (True, False):
+        eng.engine.model.use_skinny = use
+        eng.clear_kv()
+        pos = torch.arange(160, device=DEV)
+        # prefill 126 tokens (general path in both runs), then a 34-token tree level
+        eng.inference(input_ids=ids[:, :126], storage_ids=pos[:126], position_ids=pos[None, :126], attn_mask=None,
+                      tree=TreeContext(0, 126, g.size, bm, 126))
+        lv = eng.inference(input_ids=ids[:, 126:160], storage_ids=pos[126:160], position_ids=pos[None, 126:160],
+                           attn_mask=None, tree=TreeContext(126, 126, g.size, bm, 160))
+        outs.append(lv.float())
+        caches.append(eng.engine.kv_cache.k_cache[:, :, :, :160].float().clone())
+    assert (outs[0] - outs[1]).abs().max() < 6e-2          # logits of magnitude ~10: a few fp16 ulps
+    assert (outs[0].argmax(-1) == outs[1].argmax(-1)).float().mean() > 0.9
+    assert (caches[0] - caches[1]).abs().max() < 2e-2

@@ -435,3 +435,35 @@ def test_top_p_filter(ops, V, gain, top_p):
             d = dev(z[f"wor{i}/logits"])
             ops.top_p_filter(d, 0.9, 0.6)
             assert (np.isinf(d.cpu().numpy()) != np.isinf(z[f"wor{i}/topp09"])).sum(axis=1).max() <= 6
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 2304, 768), (34, 768, 768), (19, 3072, 768), (31, 768, 3072), (64, 32000, 768),
+                                    (16, 96, 128)])
+def test_linear_skinny(ops, m, n, k):
+    """Fused skinny projections vs the unfused expression on the GPU (same fp16 rounding points; only the
+    fp32 accumulation order differs from hipBLASLt): plain, RMSNorm prologue, SiLU*up epilogue, residual."""
+    g = torch.Generator(device=DEV).manual_seed(m * 7 + n)
+    a = (torch.randn(m, k, generator=g, device=DEV)).half()
+    w = (torch.randn(n, k, generator=g, device=DEV) * 0.05).half()
+    ln = (1 + 0.1 * torch.randn(k, generator=g, device=DEV)).half()
+    res = torch.randn(m, n, generator=g, device=DEV).half()
+
+    def norm(x):
+        xf = x.float()
+        return ln * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).half()
+    tol = dict(atol=2e-2, rtol=2e-2)
+    out = torch.empty(m, n, dtype=torch.float16, device=DEV)
+    ops.linear_skinny(a, w, out)
+    assert torch.allclose(out.float(), (a.float() @ w.float().t()), **tol)
+    ops.linear_skinny(a, w, out, ln_w=ln, eps=1e-6)
+    assert torch.allclose(out.float(), norm(a).float() @ w.float().t(), **tol)
+    out2 = res.clone()
+    ops.linear_skinny(a, w, out2, res_out=out2)                   # in-place residual
+    assert torch.allclose(out2.float(), ((a.float() @ w.float().t()).half() + res).float(), **tol)
+    if n % 2 == 0:
+        h = n // 2
+        o3 = torch.empty(m, h, dtype=torch.float16, device=DEV)
+        ops.linear_skinny(a, w, o3, ln_w=ln, eps=1e-6, silu=True)
+        y = (norm(a).float() @ w.float().t()).half()
+        want = (torch.nn.functional.silu(y[:, :h]) * y[:, h:]).float()
+        assert torch.allclose(o3.float(), want, **tol)
