@@ -116,7 +116,8 @@ class _GraphRunner:
         return self.engine.model_run(input_ids=self.input_ids, storage_ids=self.storage_ids,
                                      position_ids=self.position_ids, attention_mask=self.mask, tree=self.tree)
 
-    def replay(self, input_ids, storage_ids, position_ids, attn_mask=None, tree: TreeContext | None = None):
+    def replay(self, input_ids, storage_ids, position_ids, attn_mask=None, tree: TreeContext | None = None,
+               borrow: bool = False):
         self.input_ids.copy_(input_ids)
         self.storage_ids.copy_(storage_ids)
         self.position_ids.copy_(position_ids)
@@ -127,7 +128,8 @@ class _GraphRunner:
             get_ops().store_i32(self.ctx, [tree.q_slot0, tree.gt, tree.kv_len])
         self.graph.replay()
         kv.note_written(self.q_len)          # host-side bookkeeping the captured forward cannot replay
-        return self.logits.clone()
+        # `borrow`: the caller consumes the static output before the next replay (stream order), no clone
+        return self.logits if borrow else self.logits.clone()
 
 
 class GraphInferenceEngine:
@@ -198,7 +200,7 @@ class GraphInferenceEngine:
     @torch.inference_mode()
     def graph_inference(self, input_ids: torch.LongTensor, storage_ids: torch.LongTensor,
                         position_ids: Optional[torch.LongTensor] = None, attn_mask: Optional[torch.Tensor] = None,
-                        debug: bool = False, tree: Optional[TreeContext] = None):
+                        debug: bool = False, tree: Optional[TreeContext] = None, borrow: bool = False):
         dec_length = input_ids.shape[1]
         if debug:
             assert input_ids.shape[0] == 1
@@ -209,7 +211,7 @@ class GraphInferenceEngine:
         if tree is not None:
             runner = self.tree_callables.get((dec_length, tree.bitmask.data_ptr()))
             if runner is not None:
-                return runner.replay(input_ids, storage_ids, position_ids, tree=tree)
+                return runner.replay(input_ids, storage_ids, position_ids, tree=tree, borrow=borrow)
             return self.inference(input_ids, storage_ids, position_ids, attn_mask, tree=tree)
         runner = self.callables.get(dec_length)
         if runner is not None:

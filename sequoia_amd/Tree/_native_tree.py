@@ -121,7 +121,7 @@ class NativeTree(Tree):
             input_ids=self.tokens[self.draft_kv_len:end_pos].unsqueeze(0),
             position_ids=self.position_ids[start_pos:end_pos].unsqueeze(0),
             attn_mask=None, storage_ids=self.storage_ids[self.draft_kv_len:end_pos],
-            tree=self._ctx(self.draft_kv_len, end_pos))
+            tree=self._ctx(self.draft_kv_len, end_pos), borrow=True)
         self.draft_kv_len = end_pos
         first = start_pos - self.ground_truth_len + 1
         self.draft_logits[first:first + total_branch] = logits[0][-total_branch:]
@@ -147,10 +147,15 @@ class NativeTree(Tree):
         end_pos = self.num_nodes
         if benchmark:
             _sync(self.device); t1 = time.time()
-        out = self.target_model_engine.inference(
+        # a captured verify graph (q_len == tree size) is used when the engine has one; otherwise eager,
+        # like the reference's GraphInferenceEngineTG.inference (Engine/Engine.py:274-282)
+        tgt = self.target_model_engine
+        run = getattr(tgt, "graph_inference", None)
+        kw = dict(borrow=True) if run is not None else {}
+        out = (run or tgt.inference)(
             input_ids=self.tokens[start_pos:end_pos].unsqueeze(0),
             position_ids=self.position_ids[start_pos:end_pos].unsqueeze(0), attn_mask=None,
-            storage_ids=self.storage_ids[start_pos:end_pos], tree=self._ctx(start_pos, end_pos))
+            storage_ids=self.storage_ids[start_pos:end_pos], tree=self._ctx(start_pos, end_pos), **kw)
         if benchmark:
             _sync(self.device); t2 = time.time()
         self.target_logits = out[0][gt - 1 - start_pos:] if start_pos == 0 else out[0][-new_node_num:]
@@ -201,7 +206,8 @@ class NativeTree(Tree):
         self.num_nodes = new_gt
         logits = self.draft_model_engine.graph_inference(
             input_ids=self.tokens[a:new_gt].unsqueeze(0), storage_ids=self.storage_ids[a:new_gt],
-            position_ids=self.position_ids[a:new_gt].unsqueeze(0), attn_mask=None, tree=self._ctx(a, new_gt))
+            position_ids=self.position_ids[a:new_gt].unsqueeze(0), attn_mask=None, tree=self._ctx(a, new_gt),
+            borrow=True)
         self.draft_logits[0] = logits[0, -1]
         self.draft_kv_len = new_gt
         self.target_kv_len = a
