@@ -95,7 +95,8 @@ class _GraphRunner:
             self.mask = torch.zeros((1, 1, q_len, M), dtype=engine.dtype, device=dev)
         else:
             self.ctx = torch.tensor([0, 1, q_len], dtype=torch.int32, device=dev)
-            self.tree = TreeContext(q_slot0=0, gt=1, n_tree=n_tree, bitmask=bitmask, kv_len=q_len, ctx=self.ctx)
+            self.tree = TreeContext(q_slot0=0, gt=1, n_tree=n_tree, bitmask=bitmask, kv_len=q_len, ctx=self.ctx,
+                                    contiguous_slots=True)
         kv = engine.kv_cache
         saved = (kv.kv_offset, kv.dirty_end)
         s = torch.cuda.Stream()
@@ -209,7 +210,8 @@ class GraphInferenceEngine:
             if attn_mask is not None:
                 assert attn_mask.shape[2] == dec_length and attn_mask.shape[3] == self.engine.max_length
         if tree is not None:
-            runner = self.tree_callables.get((dec_length, tree.bitmask.data_ptr()))
+            # the captured forwards assume storage_ids == q_slot0 + arange(q_len) (fused RoPE + attention)
+            runner = self.tree_callables.get((dec_length, tree.bitmask.data_ptr())) if tree.contiguous_slots else None
             if runner is not None:
                 return runner.replay(input_ids, storage_ids, position_ids, tree=tree, borrow=borrow)
             return self.inference(input_ids, storage_ids, position_ids, attn_mask, tree=tree)

@@ -9,12 +9,18 @@ projections stay on PyTorch (hipBLASLt) as BASELINE.json's north_star prescribes
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
 import torch.nn.functional as F
 
 from ..ops import get_ops
+
+# Fused RoPE + KV write + attention launch (sq_rope_tree_attention_f16): bit-identical to the two-kernel
+# path but measured slower on the 7B verify shape (13.6 us vs 8.4 + 2.5 us: every workgroup rotates the new
+# keys it reads and the strided qkv rows load worse than cache rows) and a tie on draft levels -> opt-in.
+FUSE_ROPE_ATTENTION = os.environ.get("SEQUOIA_FUSE_ROPE", "0") == "1"
 
 
 def rope_tables(head_dim: int, max_pos: int, base: float, device, dtype=torch.float16):
@@ -39,6 +45,7 @@ class TreeContext:
     bitmask: torch.Tensor          # int64 [n_tree, words] (uint64 bit patterns)
     kv_len: int
     ctx: torch.Tensor | None = None
+    contiguous_slots: bool = False     # storage_ids == q_slot0 + arange(q_len): enables the fused RoPE+attention launch
 
 
 @dataclass
@@ -58,11 +65,16 @@ def attention_core(qkv, layer_idx: int, dims, kv_cache, cos, sin, position_ids, 
     ops = get_ops()
     q_len = qkv.shape[0]
     n_heads, h_kv, d = dims.local_heads, dims.local_kv_heads, dims.head_dim
-    q_rot = torch.empty((n_heads, q_len, d), dtype=qkv.dtype, device=qkv.device)
     k_layer, v_layer = kv_cache.k_cache[layer_idx, 0], kv_cache.v_cache[layer_idx, 0]
-    ops.rope_kv_write(qkv, q_rot, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d)
     attn = torch.empty((q_len, n_heads * d), dtype=qkv.dtype, device=qkv.device)
     scale = 1.0 / math.sqrt(d)
+    if tree is not None and tree.contiguous_slots and FUSE_ROPE_ATTENTION:
+        # one launch: RoPE of q and the new k, KV slot write, tree attention
+        ops.rope_tree_attention(qkv, k_layer, v_layer, cos, sin, position_ids, attn, n_heads, h_kv, d, tree.kv_len,
+                                scale, tree.q_slot0, tree.gt, tree.n_tree, tree.bitmask, ctx=tree.ctx)
+        return attn
+    q_rot = torch.empty((n_heads, q_len, d), dtype=qkv.dtype, device=qkv.device)
+    ops.rope_kv_write(qkv, q_rot, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d)
     if tree is not None:
         ops.tree_attention(q_rot, k_layer, v_layer, attn, tree.kv_len, scale, q_slot0=tree.q_slot0, gt=tree.gt,
                            n_tree=tree.n_tree, bitmask=tree.bitmask, ctx=tree.ctx)

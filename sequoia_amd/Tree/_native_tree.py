@@ -94,8 +94,9 @@ class NativeTree(Tree):
 
     # ---- helpers --------------------------------------------------------------------------------
     def _ctx(self, q_slot0: int, kv_len: int) -> TreeContext:
+        # storage_ids = arange(M) (Tree/SpecTree.py:63): the queries' KV slots are q_slot0 + arange(q_len)
         return TreeContext(q_slot0=q_slot0, gt=self.ground_truth_len, n_tree=self.tree_size,
-                           bitmask=self.gdev["bitmask"], kv_len=kv_len)
+                           bitmask=self.gdev["bitmask"], kv_len=kv_len, contiguous_slots=True)
 
     def _sample_level(self, i: int, lv: dict):
         raise NotImplementedError
