@@ -102,7 +102,7 @@ class Loop:
                              sample_gather_indices=None)
         self.cur_len = len(p)
 
-    def run_steps(self, k_steps, timed=True):
+    def run_steps(self, k_steps):
         """Run exactly k_steps speculation steps; per-prompt setup (tree constructor + draft
         prefill) is outside the timed brackets like the reference (tests/testbed.py:67-79).
         Returns (seconds, new_tokens, steps)."""
@@ -131,8 +131,7 @@ def kernel_rooflines(cfg, loop, device):
     (SURVEY.md §8d formulas)."""
     from sequoia_amd.ops import get_ops
     ops = get_ops()
-    tgt, drf = loop.target.engine, loop.draft.engine
-    gm, gdev = loop.tree.gm if loop.tree else None, None
+    tgt = loop.target.engine
     from sequoia_amd.Tree.Tree import growmap_on_device
     g, gdev = growmap_on_device(loop.grow_map, device)
     n, V, M = g.size, 32000, cfg["M"]

@@ -113,24 +113,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u32_wide_dpp(uint32_t v) 
 }
 
 // wave-level reductions over 64 lanes (all lanes get the result) ------------------------------
-__device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
-        v = v > w ? v : w;
-    }
-    return v;
-}
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
