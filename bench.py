@@ -27,102 +27,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-MODELS = {
-    "B": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="A100-CNN-68m-7b-stochastic",
-              mode="stochastic", M=384),
-    "C": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="8x8-tree", mode="greedy", M=384),
-    "D": dict(draft="princeton-nlp/Sheared-LLaMA-1.3B", target="meta-llama/Llama-2-13b-hf",
-              growmap="A100-CNN-160m-13b-stochastic", mode="stochastic", M=384),
-    # 70B target sharded tensor-parallel over all launched ranks (replaces the reference's host offload);
-    # every rank runs the replicated draft + verifier, so N ranks serve ONE request stream ("strong")
-    "E": dict(draft="meta-llama/Llama-2-7b-hf", target="meta-llama/Llama-2-70b-hf", growmap="64x2-tree",
-              mode="stochastic", M=1024, tp=True),
-}
-
-
-def load_prompts():
-    with open(os.path.join(REPO, "sequoia_amd", "growmaps", "c4_small_prompts.json")) as f:
-        return json.load(f)["prompts"]
-
-
-def build(cfg, device, pair, seed_d=1, seed_t=2):
-    from sequoia_amd.Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
-    from sequoia_amd.growmap import GrowMap
-    M = cfg["M"]
-    if pair == "calibrated":
-        from sequoia_amd.synthetic import calibrated_pair_specs
-        tpw = int(os.environ.get("WORLD_SIZE", "1")) if cfg.get("tp") else 1
-        tpr = int(os.environ.get("RANK", "0")) if cfg.get("tp") else 0
-        dspec, tspec = calibrated_pair_specs(cfg["draft"], cfg["target"], device, tp_world=tpw, tp_rank=tpr)
-    else:
-        dspec, tspec = f"random:{cfg['draft']}:seed={seed_d}", f"random:{cfg['target']}:seed={seed_t}"
-    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
-    if cfg.get("tp"):
-        from sequoia_amd.Engine.offload_engine import OffloadEngine
-        target = OffloadEngine(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
-    else:
-        target = GraphInferenceEngineTG(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
-    gm = GrowMap.load(cfg["growmap"])
-    return draft, target, gm
-
-
-class Loop:
-    """simulation_fast (tests/testbed.py:45-95) as a resumable step iterator."""
-
-    def __init__(self, cfg, draft, target, gm, device, prompts, use_graphs=True, T=0.6):
-        from sequoia_amd.Tree.GreedyTree import GreedyTree
-        from sequoia_amd.Tree.SpecTree import SpecTree
-        from sequoia_amd.Tree.Tree import growmap_on_device
-        self.cfg, self.draft, self.target, self.device, self.prompts, self.T = cfg, draft, target, device, prompts, T
-        self.grow_map = gm.to_reference_dict()
-        self.cls = SpecTree if cfg["mode"] == "stochastic" else GreedyTree
-        M = cfg["M"]
-        self.attn_mask = torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16, device=device)
-        self.position_ids = torch.zeros(M, dtype=torch.long, device=device)
-        g, gdev = growmap_on_device(self.grow_map, device)
-        if use_graphs:
-            lens = sorted({lv.total for lv in g.levels} | {1})
-            draft.initialize_cuda_graph(lens, tree_bitmask=gdev["bitmask"], n_tree=g.size)
-            if hasattr(target, "initialize_cuda_graph"):
-                target.initialize_cuda_graph([g.size], tree_bitmask=gdev["bitmask"], n_tree=g.size)
-        self.pi = 0
-        self.tree = None
-        self.cur_len = 0
-
-    def _new_prompt(self):
-        self.draft.clear_kv(); self.target.clear_kv()
-        p = torch.tensor(self.prompts[self.pi % len(self.prompts)][:128], dtype=torch.long)
-        self.pi += 1
-        M = self.cfg["M"]
-        self.tree = self.cls(prefix=p, device=self.device, temperature=self.T, top_p=1.0, draft_kv_len=0,
-                             target_kv_len=0, draft_model_engine=self.draft, target_model_engine=self.target,
-                             max_length=M, max_target_seq=M, grow_map=self.grow_map, attn_mask=self.attn_mask,
-                             sequence=None, new_tokens_buffer=None, parents_buffer=None,
-                             position_ids=self.position_ids, residual_graph=None, sampling_callables=None,
-                             sample_gather_indices=None)
-        self.cur_len = len(p)
-
-    def run_steps(self, k_steps):
-        """Run exactly k_steps speculation steps; per-prompt setup (tree constructor + draft
-        prefill) is outside the timed brackets like the reference (tests/testbed.py:67-79).
-        Returns (seconds, new_tokens, steps)."""
-        total_t, new_tok, done = 0.0, 0, 0
-        while done < k_steps:
-            if self.tree is None:
-                self._new_prompt()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            while done < k_steps and self.tree is not None:
-                self.tree.construct_grow_map()
-                valid, _, _, terminate = self.tree.verify()
-                new_tok += valid.shape[0] - self.cur_len
-                self.cur_len = valid.shape[0]
-                done += 1
-                if terminate or self.cur_len >= 256 or int(valid[-1]) in (0, 2):
-                    self.tree = None
-            torch.cuda.synchronize()
-            total_t += time.perf_counter() - t1
-        return total_t, new_tok, done
+from sequoia_amd.harness import MODELS, Loop, build, load_prompts  # noqa: E402
 
 
 def kernel_rooflines(cfg, loop, device):
@@ -278,6 +183,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave PyTorch's GEMM algorithm choice at its default")
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--growmap", default=None, help="override the config's growmap: bundled name or path (.json / reference .pt)")
+    ap.add_argument("--no-autoregressive", action="store_true", help="skip the target-only baseline (simulation_baseline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -291,7 +198,9 @@ def main():
     torch.cuda.set_device(local)
     torch.manual_seed(17 + rank)
 
-    cfg = MODELS[args.config]
+    cfg = dict(MODELS[args.config])
+    if args.growmap:
+        cfg["growmap"] = args.growmap
     gemm_tuned = False
     if not args.no_gemm_tuning:
         from sequoia_amd import gemm_tuning
@@ -342,6 +251,13 @@ def main():
                     time_per_step_us=per_step[dom] * 1e6)
         kernels = {k: dict(avg_us=v["seconds"] * 1e6, gbps=v["bytes"] / v["seconds"] / 1e9,
                            per_step_us=per_step[k] * 1e6) for k, v in kr.items()}
+        autoreg = None
+        if not args.no_autoregressive and world == 1:
+            # the reference's own comparison point (tests/testbed.py:99-143): the target alone, 1 token / forward
+            from sequoia_amd.harness import AutoregressiveLoop
+            draft.clear_kv(); target.clear_kv()
+            autoreg = AutoregressiveLoop(cfg, target, device, prompts).run(3)
+            autoreg["speedup"] = (new_tok / secs) / autoreg["tokens_per_s"]
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
@@ -353,14 +269,14 @@ def main():
                     steps=args.steps, warmup=args.warmup, ms_per_step=secs / args.steps * 1e3,
                     higher_is_better=True, scaling="strong" if tp_mode else "weak", vs_baseline=None, dtype="f16", data="synthetic",
                     config=dict(workload=f"config {args.config}: {cfg['draft']} -> {cfg['target']} architectures "
-                                         f"({args.pair} random-init weights), growmap {cfg['growmap']} "
+                                         f"({args.pair} random-init weights), growmap {os.path.basename(str(cfg['growmap']))} "
                                          f"({gm.size}-node tree), T=0.6, top_p=1.0, M={cfg['M']}, 128-token c4_small "
                                          f"prompts, generate to 256",
                                 parallelism=(f"tp{world}" if tp_mode else ("replicas" if world > 1 else "single")), graphs=not args.no_graphs,
                                 gemm="torch TunableOp (hipBLASLt/rocBLAS solution picked per shape)" if gemm_tuned
                                 else "torch default"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs,
-                    roofline=roof, kernels=kernels, cpu_baseline=cpu)
+                    roofline=roof, kernels=kernels, autoregressive_baseline=autoreg, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

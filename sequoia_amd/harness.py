@@ -1,0 +1,185 @@
+"""The reference's evaluation loop (tests/testbed.py:45-95, `simulation_fast`) as a reusable object:
+engine construction for the BASELINE.json configurations, the 128-token c4_small prompts, and a
+resumable speculation-step iterator.  Shared by bench.py, the growmap tuner and the GPU tests.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+
+def _sync(device):
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+
+MODELS = {
+    "B": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="A100-CNN-68m-7b-stochastic",
+              mode="stochastic", M=384),
+    "C": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="8x8-tree", mode="greedy", M=384),
+    "D": dict(draft="princeton-nlp/Sheared-LLaMA-1.3B", target="meta-llama/Llama-2-13b-hf",
+              growmap="A100-CNN-160m-13b-stochastic", mode="stochastic", M=384),
+    # 70B target sharded tensor-parallel over all launched ranks (replaces the reference's host offload);
+    # every rank runs the replicated draft + verifier, so N ranks serve ONE request stream ("strong")
+    "E": dict(draft="meta-llama/Llama-2-7b-hf", target="meta-llama/Llama-2-70b-hf", growmap="64x2-tree",
+              mode="stochastic", M=1024, tp=True),
+}
+
+
+def load_prompts():
+    with open(os.path.join(_PKG, "growmaps", "c4_small_prompts.json")) as f:
+        return json.load(f)["prompts"]
+
+
+def build(cfg, device, pair, seed_d=1, seed_t=2):
+    """Draft engine, target engine and growmap of one MODELS entry.  `pair`: "calibrated" (synthetic
+    draft/target pair with a realistic acceptance rate, sequoia_amd/synthetic.py) or "random"."""
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
+    from sequoia_amd.growmap import GrowMap
+    M = cfg["M"]
+    if pair == "calibrated":
+        from sequoia_amd.synthetic import calibrated_pair_specs
+        tpw = int(os.environ.get("WORLD_SIZE", "1")) if cfg.get("tp") else 1
+        tpr = int(os.environ.get("RANK", "0")) if cfg.get("tp") else 0
+        dspec, tspec = calibrated_pair_specs(cfg["draft"], cfg["target"], device, tp_world=tpw, tp_rank=tpr)
+    else:
+        dspec, tspec = f"random:{cfg['draft']}:seed={seed_d}", f"random:{cfg['target']}:seed={seed_t}"
+    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
+    if cfg.get("tp"):
+        from sequoia_amd.Engine.offload_engine import OffloadEngine
+        target = OffloadEngine(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
+    else:
+        target = GraphInferenceEngineTG(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
+    gm = GrowMap.load(cfg["growmap"])
+    return draft, target, gm
+
+
+class Loop:
+    """simulation_fast (tests/testbed.py:45-95) as a resumable step iterator."""
+
+    def __init__(self, cfg, draft, target, gm, device, prompts, use_graphs=True, T=0.6, top_p=1.0, max_new=256, vocab=32000):
+        from sequoia_amd.Tree.GreedyTree import GreedyTree
+        from sequoia_amd.Tree.SpecTree import SpecTree
+        from sequoia_amd.Tree.Tree import growmap_on_device
+        self.cfg, self.draft, self.target, self.device, self.prompts, self.T = cfg, draft, target, device, prompts, T
+        self.top_p, self.max_new, self.vocab = top_p, max_new, vocab
+        self.grow_map = gm.to_reference_dict()
+        self.cls = SpecTree if cfg["mode"] == "stochastic" else GreedyTree
+        M = cfg["M"]
+        self.attn_mask = torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16, device=device)
+        self.position_ids = torch.zeros(M, dtype=torch.long, device=device)
+        g, gdev = growmap_on_device(self.grow_map, device)
+        if use_graphs:
+            lens = sorted({lv.total for lv in g.levels} | {1})
+            draft.initialize_cuda_graph(lens, tree_bitmask=gdev["bitmask"], n_tree=g.size)
+            if hasattr(target, "initialize_cuda_graph"):
+                target.initialize_cuda_graph([g.size], tree_bitmask=gdev["bitmask"], n_tree=g.size)
+        self.pi = 0
+        self.tree = None
+        self.cur_len = 0
+
+    def _new_prompt(self):
+        self.draft.clear_kv(); self.target.clear_kv()
+        p = torch.tensor(self.prompts[self.pi % len(self.prompts)][:128], dtype=torch.long)
+        self.pi += 1
+        M = self.cfg["M"]
+        self.tree = self.cls(prefix=p, device=self.device, temperature=self.T, top_p=self.top_p, draft_kv_len=0,
+                             target_kv_len=0, draft_model_engine=self.draft, target_model_engine=self.target,
+                             max_length=M, max_target_seq=M, grow_map=self.grow_map, attn_mask=self.attn_mask,
+                             sequence=None, new_tokens_buffer=None, parents_buffer=None,
+                             position_ids=self.position_ids, residual_graph=None, sampling_callables=None,
+                             sample_gather_indices=None, vocab_size=self.vocab)
+        self.cur_len = len(p)
+
+    def run_steps(self, k_steps, on_step=None):
+        """Run exactly k_steps speculation steps; per-prompt setup (tree constructor + draft
+        prefill) is outside the timed brackets like the reference (tests/testbed.py:67-79).
+        `on_step(tree, terminate)` is called after every verify().  Returns (seconds, new_tokens, steps)."""
+        total_t, new_tok, done = 0.0, 0, 0
+        while done < k_steps:
+            if self.tree is None:
+                self._new_prompt()
+            _sync(self.device)
+            t1 = time.perf_counter()
+            while done < k_steps and self.tree is not None:
+                self.tree.construct_grow_map()
+                valid, _, _, terminate = self.tree.verify()
+                new_tok += valid.shape[0] - self.cur_len
+                self.cur_len = valid.shape[0]
+                done += 1
+                if on_step is not None:
+                    on_step(self.tree, terminate)
+                if terminate or self.cur_len >= self.max_new or int(valid[-1]) in (0, 2):
+                    self.tree = None
+            _sync(self.device)
+            total_t += time.perf_counter() - t1
+        return total_t, new_tok, done
+
+
+class AutoregressiveLoop:
+    """The reference's autoregressive baseline (`simulation_baseline`, tests/testbed.py:99-143): the target
+    model alone, one token per forward, `softmax(logits / T)` sampled once per step.  The 1-token forward is a
+    hipGraph replay with a single-node "tree" (the query sees the committed prefix and itself); the draw is
+    sq_sample_wor_f16 with k = 1 — argmax of log(u)/p, an exact sample from p — in place of `p.multinomial(1)`.
+    The token is read back every step like the reference's EOS test (:137)."""
+
+    def __init__(self, cfg, target, device, prompts, T=0.6, max_steps=32, use_graphs=True, vocab=32000):
+        from sequoia_amd.Engine.Llama_modules import TreeContext
+        from sequoia_amd.ops import get_ops
+        self.cfg, self.target, self.device, self.prompts, self.T = cfg, target, device, prompts, T
+        self.max_steps, self.use_graphs = max_steps, use_graphs
+        self.ops = get_ops()
+        self.TreeContext = TreeContext
+        self.bitmask = torch.ones((1, 1), dtype=torch.int64, device=device)
+        if use_graphs and hasattr(target, "initialize_cuda_graph"):
+            target.initialize_cuda_graph([1], tree_bitmask=self.bitmask, n_tree=1)
+        self.rand = torch.empty((max_steps, vocab), dtype=torch.float16).uniform_().to(device)
+        self.row = torch.zeros(1, dtype=torch.int32, device=device)
+        self.tok = torch.zeros(1, dtype=torch.long, device=device)
+        self.arange = torch.arange(cfg["M"], device=device)
+        self.pi = 0
+
+    def _ctx(self, q_slot0, kv_len):
+        # gt = kv_len: the last query is tree node 0 (the root), everything before it is committed text
+        return self.TreeContext(q_slot0=q_slot0, gt=kv_len, n_tree=1, bitmask=self.bitmask, kv_len=kv_len,
+                                contiguous_slots=True)
+
+    @torch.inference_mode()
+    def run_prompt(self):
+        """One prompt: prefill (untimed) + up to max_steps decode steps.  Returns (seconds, tokens)."""
+        tgt = self.target
+        tgt.clear_kv()
+        p = torch.tensor(self.prompts[self.pi % len(self.prompts)][:128], dtype=torch.long, device=self.device)
+        self.pi += 1
+        n = len(p)
+        logits = tgt.inference(input_ids=p.unsqueeze(0), storage_ids=self.arange[:n], position_ids=self.arange[:n].unsqueeze(0),
+                               attn_mask=None, tree=self._ctx(0, n))[0, -1:]
+        run = getattr(tgt, "graph_inference", None) if self.use_graphs else None
+        kw = dict(borrow=True) if run is not None else {}
+        run = run or tgt.inference
+        _sync(self.device)
+        t0 = time.perf_counter()
+        done = 0
+        for step in range(self.max_steps):
+            self.ops.sample_wor(logits, self.rand[step:step + 1], self.row, 1, self.T, self.tok)
+            done += 1
+            if int(self.tok[0]) in (0, 2) or n + step + 1 >= self.cfg["M"]:
+                break
+            s = n + step
+            logits = run(input_ids=self.tok.unsqueeze(0), storage_ids=self.arange[s:s + 1],
+                         position_ids=self.arange[s:s + 1].unsqueeze(0), attn_mask=None, tree=self._ctx(s, s + 1), **kw)[0]
+        _sync(self.device)
+        dt = time.perf_counter() - t0
+        tgt.clear_kv()
+        return dt, done
+
+    def run(self, n_prompts=3):
+        secs = toks = 0
+        for _ in range(n_prompts):
+            dt, k = self.run_prompt()
+            secs += dt; toks += k
+        return dict(tokens_per_s=toks / secs, ms_per_token=secs / toks * 1e3, tokens=toks, prompts=n_prompts)
