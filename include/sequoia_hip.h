@@ -115,8 +115,11 @@ int sq_rope_kv_write_f16(const void* qkv, int qkv_stride, void* q_out,
  * mask_mode 0: dense additive fp16 mask [q_len][mask_stride] (the reference's attn_mask);
  * mask_mode 1: implicit tree mask = same rule as sq_tree_mask_dense_f16, query i sits at slot
  *              q_slot0 + i.
+ * mask_mode | SQ_ATT_OUT_FRAG: out is written as the fragment-major activation image
+ *              [H*D / 32][ceil(q_len / 16)][64][8] that sq_linear_ts_f16 (the o_proj) consumes.
  * d_ctx (optional, device int32[3]): when non-NULL the kernel takes {q_slot0, gt, kv_len} from
  * it instead of the by-value arguments, so a captured launch can be replayed for other steps. */
+#define SQ_ATT_OUT_FRAG 0x100
 int sq_tree_attention_f16(const void* q, const void* k_layer, const void* v_layer, void* out,
                           int q_len, int n_heads, int h_kv, int d, int m, int kv_len,
                           float scale, int mask_mode,
@@ -213,6 +216,13 @@ int sq_rmsnorm_f16(const void* x, const void* weight, void* out, int rows, int h
  * sum_out = x + residual (fp16 add; sum_out may alias residual), out = rmsnorm(sum_out)*weight */
 int sq_add_rmsnorm_f16(const void* x, const void* residual, void* sum_out, const void* weight,
                        void* out, int rows, int hidden, float eps, void* stream);
+/* The same three row-wise ops with the output written as the fragment-major activation image
+ * [hidden / 32][ceil(rows / 16)][64][8] of sq_linear_ts_f16 (hidden % 32 == 0); identical arithmetic.    */
+int sq_rmsnorm_frag_f16(const void* x, const void* weight, void* out_frag, int rows, int hidden, float eps, void* stream);
+int sq_add_rmsnorm_frag_f16(const void* x, const void* residual, void* sum_out, const void* weight, void* out_frag,
+                            int rows, int hidden, float eps, void* stream);
+int sq_silu_mul_frag_f16(const void* gate_up, void* out_frag, int rows, int inter, void* stream);
+
 /* LlamaMLP_FI (Engine/Llama_modules.py:270-271): out = act_fn(gate) * up in fp16.
  * gate_up: fp16 [rows][2*inter] packed gate | up (one fused GEMM); out: fp16 [rows][inter].  */
 int sq_silu_mul_f16(const void* gate_up, void* out, int rows, int inter, void* stream);
@@ -228,6 +238,41 @@ int sq_silu_mul_f16(const void* gate_up, void* out, int rows, int inter, void* s
 int sq_linear_skinny_f16(const void* a, int lda, const void* res_in, void* sum_out, const void* ln_w,
                          float eps, const void* w, const void* res_out, void* out, int ldo,
                          int m, int n, int k, int silu, void* stream);
+
+/* Fragment-major operand images of the tall-skinny linear layer (MFMA 16x16x32 operand order: lane =
+ * (k / 8 % 4) * 16 + row % 16 holds 8 consecutive k of its row, so every wave-wide operand load is 1 KB contiguous):
+ *   weights      w_f[n / 16][k / 32][lane][8]   <- w [n][k] row-major (nn.Linear.weight), once at load;
+ *   activations  x_f[k / 32][ceil(m / 16)][lane][8], rows >= m zero  <- x [m][ldx] row-major.
+ * n % 16 == 0, k % 32 == 0; out of place.                                                                    */
+int sq_repack_linear_weight_f16(const void* w, void* w_frag, int n, int k, void* stream);
+int sq_repack_rows_frag_f16(const void* x, int ldx, void* x_frag, int m, int k, void* stream);
+
+/* Tall-skinny linear layer of a tree forward (m <= 128 rows: one tree / tree level), nn.Linear semantics
+ * out = a . w^T, fp32 accumulation, fp16 output -- the dense projections of LlamaAttention_FI/TG and LlamaMLP_FI
+ * (Engine/Llama_modules.py:104-112,138,199-207,256,262-271) when q_len <= 128, as an HBM weight stream over
+ * fragment-major operands (above).  The launch has tiles x splits workgroups: the n_out / 16 column units are
+ * partitioned over `tiles` workgroups (<= 4 units each; silu: <= 3, <= 2 when m > 64), K over `splits`.
+ *   splits == 1, silu != 0   : w_frag holds gate tiles [0, n_out/16) then up tiles;
+ *                              out = h(h(silu(h(g))) * h(u))                                         (:271)
+ *   splits == 1, res != NULL : out = h(h(acc) + res) (fp16 add, the decoder layer's skip connection
+ *                              :341-346; out may alias res; row-major output only)
+ *   splits == 1, out_frag    : out is written as the fragment-major activation image of the next layer
+ *                              ([n_out / 32][ceil(m / 16)][64][8]; n_out % 32 == 0), else row-major [m][ldo]
+ *   splits  > 1              : no out / res / silu; split s writes its fp32 partial product to
+ *                              slab[s][m][n_out] (sq_linear_ts_workspace_bytes bytes); the consumer
+ *                              (sq_add_rmsnorm_slabs_f16) sums the splits in order.
+ * k % 32 == 0, n_out % 16 == 0, 16-byte aligned pointers.                                                 */
+size_t sq_linear_ts_workspace_bytes(int m, int n_out, int splits);
+int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const void* res, void* out, int ldo, int out_frag, int m,
+                     int n_out, int k, int silu, int tiles, int splits, void* slab, size_t slab_bytes, void* stream);
+
+/* Residual add + RMSNorm fed by a split-K linear layer: x = h(sum_s slab[s]) (the layer's fp16 output),
+ * then exactly sq_add_rmsnorm_f16: sum_out = x + residual (fp16), out = RMSNorm(sum_out) * weight
+ * (Engine/Llama_modules.py:282-288,341-346).  out == NULL skips the normalisation (last layer's skip add
+ * feeding the final norm is done by a separate call); out_frag != 0 writes `out` fragment-major.
+ * slab: fp32 [splits][rows][hidden].                                                                  */
+int sq_add_rmsnorm_slabs_f16(const void* slab, int splits, const void* residual, const void* weight, void* sum_out,
+                             void* out, int out_frag, int rows, int hidden, float eps, void* stream);
 
 #ifdef __cplusplus
 }

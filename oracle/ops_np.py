@@ -402,3 +402,61 @@ def verify_greedy(target_logits16, tokens, successors, gt):
         tokens[a] = bonus
     return dict(accept_len=a, n_tree=len(slots), bonus=bonus, terminal=int(terminal), reason=reason,
                 gt=gt, last_node=node, slots=slots, target_token=tgt)
+
+
+# ---- tall-skinny linear layers (sequoia_amd/csrc/ts_linear.hip) ------------------------------------------
+# Restates nn.Linear as the reference uses it (Engine/Llama_modules.py:104-112,138,256,262-271: fp16 weights and
+# activations, fp32 accumulation inside the GEMM, fp16 output) plus the operand images the kernel reads.
+def frag_rows(x16, mtp=None):
+    """[m, k] -> fragment-major image [k/32, mtp, 64, 8]: lane = (k/8 % 4) * 16 + row % 16; rows >= m are zero."""
+    m, k = x16.shape
+    mtp = mtp or (m + 15) // 16
+    pad = np.zeros((mtp * 16, k), dtype=x16.dtype)
+    pad[:m] = x16
+    # [mt, r, kb, g, j] -> [kb, mt, g, r, j]
+    return np.ascontiguousarray(pad.reshape(mtp, 16, k // 32, 4, 8).transpose(2, 0, 3, 1, 4)).reshape(k // 32, mtp, 64, 8)
+
+
+def unfrag_rows(xf, m, k):
+    mtp = xf.shape[1]
+    full = xf.reshape(k // 32, mtp, 4, 16, 8).transpose(1, 3, 0, 2, 4).reshape(mtp * 16, k)
+    return np.ascontiguousarray(full[:m])
+
+
+def frag_weight(w16):
+    """[n, k] -> [n/16, k/32, 64, 8] (weights: tile-major)."""
+    n, k = w16.shape
+    return np.ascontiguousarray(w16.reshape(n // 16, 16, k // 32, 4, 8).transpose(0, 2, 3, 1, 4)).reshape(n // 16, k // 32, 64, 8)
+
+
+def silu_mul_f16(g16, u16):
+    """h(h(silu(g)) * u)  (LlamaMLP_FI: act_fn(gate_proj(x)) * up_proj(x), fp16 tensors)."""
+    gf = f(g16)
+    s = h(gf / (np.float32(1.0) + np.exp(-gf, dtype=np.float32)))
+    return h(f(s) * f(u16))
+
+
+def linear_f16(a16, w16, res16=None, silu=False):
+    """a [m, k] . w [n, k]^T with fp32 accumulation and fp16 output; silu: w = [gate rows | up rows];
+    res: h(h(acc) + res)."""
+    acc = f(a16) @ f(w16).T
+    if silu:
+        n = w16.shape[0] // 2
+        return silu_mul_f16(h(acc[:, :n]), h(acc[:, n:]))
+    out = h(acc)
+    if res16 is not None:
+        out = h(f(out) + f(res16))
+    return out
+
+
+def add_rmsnorm_slabs(slabs32, res16, weight16, eps):
+    """slabs [splits, m, n] fp32 -> (sum_out, normed): x = h(((s0 + s1) + s2) ...), sum = h(x + res), RMSNorm as
+    LlamaRMSNorm_FI (Engine/Llama_modules.py:282-288)."""
+    acc = slabs32[0].astype(np.float32)
+    for s in range(1, slabs32.shape[0]):
+        acc = acc + slabs32[s]
+    total = h(f(h(acc)) + f(res16))
+    xf = f(total)
+    var = (xf * xf).mean(-1, keepdims=True, dtype=np.float32)
+    nrm = h(xf * (np.float32(1.0) / np.sqrt(var + np.float32(eps))))
+    return total, h(f(weight16) * f(nrm))

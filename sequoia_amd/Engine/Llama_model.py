@@ -21,6 +21,8 @@ import torch.nn.functional as F
 
 from ..ops import get_ops
 from .Llama_modules import LayerWeights, TreeContext, attention_block, attention_core, mlp_block, rope_tables
+from .ts_linear import MAX_ROWS as TS_MAX_ROWS
+from .ts_linear import TsLinearSet, forward_ts
 
 # public HF configs of the model families the reference's scripts name (tests/run_A100.sh etc.)
 KNOWN_ARCHS = {
@@ -271,6 +273,8 @@ class _LlamaForCausalLM:
         # glue launches on MI355X (9.4 vs 4.7 us for the 68m qkv projection) -> opt-in
         self.use_skinny = os.environ.get("SEQUOIA_SKINNY", "0") == "1"
         self.skinny_max_hidden = int(os.environ.get("SEQUOIA_SKINNY_MAX_HIDDEN", "1024"))
+        # tall-skinny projections for tree forwards (<= 128 rows): fragment-major weight stream, Engine/ts_linear.py
+        self.ts = TsLinearSet(weights, self.dims) if TsLinearSet.supported(weights, self.dims, reduce_fn) else None
         self.reduce_fn = reduce_fn                  # TP all-reduce hook (None on one GPU)
         self.gather_logits_fn = gather_logits_fn    # TP vocab all-gather hook
 
@@ -306,6 +310,8 @@ class _LlamaForCausalLM:
             if dense.dtype != self.dtype:
                 dense = dense.to(self.dtype)
         x = F.embedding(input_ids[0], W.embed)                      # [q, hidden]
+        if self.ts is not None and q_len <= TS_MAX_ROWS:
+            return forward_ts(self, self.ts, x, q_len, pos, storage_ids, dense, tree, kv_cache)
         if self._skinny_ok(q_len, ops):
             return self._forward_skinny(x, q_len, pos, storage_ids, dense, tree, kv_cache, ops)
         hbuf = torch.empty_like(x)

@@ -59,16 +59,19 @@ class LayerWeights:
 
 
 def attention_core(qkv, layer_idx: int, dims, kv_cache, cos, sin, position_ids, storage_ids, dense_mask,
-                   tree: TreeContext | None):
+                   tree: TreeContext | None, out_frag: bool = False):
     """qkv: [q, (H + 2 H_kv) D] packed projections.  RoPE + KV slot write + tree-batched attention;
-    returns the attention output [q, H D] (the o_proj input)."""
+    returns the attention output [q, H D] (the o_proj input), or with out_frag its fragment-major image
+    (the operand layout of the tall-skinny o_proj, Engine/ts_linear.py)."""
     ops = get_ops()
     q_len = qkv.shape[0]
     n_heads, h_kv, d = dims.local_heads, dims.local_kv_heads, dims.head_dim
     k_layer, v_layer = kv_cache.k_cache[layer_idx, 0], kv_cache.v_cache[layer_idx, 0]
-    attn = torch.empty((q_len, n_heads * d), dtype=qkv.dtype, device=qkv.device)
+    attn = torch.empty(ops.frag_shape(q_len, n_heads * d) if out_frag else (q_len, n_heads * d), dtype=qkv.dtype,
+                       device=qkv.device)
     scale = 1.0 / math.sqrt(d)
-    if tree is not None and tree.contiguous_slots and FUSE_ROPE_ATTENTION:
+    frag_kw = dict(out_frag=True) if out_frag else {}
+    if tree is not None and tree.contiguous_slots and FUSE_ROPE_ATTENTION and not out_frag:
         # one launch: RoPE of q and the new k, KV slot write, tree attention
         ops.rope_tree_attention(qkv, k_layer, v_layer, cos, sin, position_ids, attn, n_heads, h_kv, d, tree.kv_len,
                                 scale, tree.q_slot0, tree.gt, tree.n_tree, tree.bitmask, ctx=tree.ctx)
@@ -77,14 +80,14 @@ def attention_core(qkv, layer_idx: int, dims, kv_cache, cos, sin, position_ids, 
     ops.rope_kv_write(qkv, q_rot, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d)
     if tree is not None:
         ops.tree_attention(q_rot, k_layer, v_layer, attn, tree.kv_len, scale, q_slot0=tree.q_slot0, gt=tree.gt,
-                           n_tree=tree.n_tree, bitmask=tree.bitmask, ctx=tree.ctx)
+                           n_tree=tree.n_tree, bitmask=tree.bitmask, ctx=tree.ctx, **frag_kw)
     else:
         if dense_mask is None:
             raise ValueError("attention needs either a dense additive mask or a TreeContext")
         kv_len = dense_mask.shape[-1]
         if kv_len > kv_cache.max_length:
             raise ValueError(f"Attention mask should cover at most {kv_cache.max_length} key slots, got {kv_len}")
-        ops.tree_attention(q_rot, k_layer, v_layer, attn, kv_len, scale, dense_mask=dense_mask)
+        ops.tree_attention(q_rot, k_layer, v_layer, attn, kv_len, scale, dense_mask=dense_mask, **frag_kw)
     return attn
 
 

@@ -1,0 +1,294 @@
+"""Tall-skinny linear layers for tree forwards (q_len <= 128): weight images, launch plans, forward.
+
+The dense projections of a tree forward multiply <= 128 activation rows by every weight of the model — an
+HBM stream of the weights.  `sq_linear_ts_f16` (csrc/ts_linear.hip) runs them from fragment-major operand
+images; this module owns what surrounds the kernel on the host:
+
+  * the fragment-major copies of a model's projection weights (made once, on first use);
+  * a launch plan per (projection shape, row-tile count): (tiles, splits) of the kernel, or "torch" when
+    PyTorch's hipBLASLt GEMM is the faster one for that shape (the 128-row gate_up / lm_head shapes).  Plans for
+    the shapes of the bundled configurations are shipped (ts_plans_gfx950.json, measured on MI355X); unknown
+    shapes are timed once, outside any graph capture, against torch on the same weights;
+  * the decoder forward that threads fragment-major activations between the producers (RMSNorm, attention,
+    SwiGLU epilogue) and the projections.  Rounding points are those of the general path
+    (Llama_model._LlamaForCausalLM.forward); only the fp32 summation order inside a projection differs.
+
+Reference lines replaced: LlamaAttention_FI/TG q/k/v/o projections (Engine/Llama_modules.py:104-112,138,199-207,256),
+LlamaMLP_FI (:262-271), the decoder layer's residual adds and norms (:282-288,341-346), lm_head
+(Engine/Llama_model.py:280-283).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import torch
+import torch.nn.functional as F
+
+from ..ops import get_ops
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLAN_FILE = os.path.join(_PKG, "ts_plans_gfx950.json")
+MAX_ROWS = 128
+ENABLED = os.environ.get("SEQUOIA_TS_LINEAR", "1") != "0"
+
+_SHIPPED = None
+
+
+def shipped_plans() -> dict:
+    global _SHIPPED
+    if _SHIPPED is None:
+        try:
+            with open(PLAN_FILE) as f:
+                _SHIPPED = json.load(f)["plans"]
+        except (OSError, ValueError, KeyError):
+            _SHIPPED = {}
+    return _SHIPPED
+
+
+def plan_key(n_out: int, k: int, silu: bool, mtp: int) -> str:
+    return f"{n_out}x{k}{'s' if silu else ''}@{mtp}"
+
+
+SPLITTABLE = ("o", "down")          # projections whose consumer is the residual add + RMSNorm (reads the slabs)
+MAX_SPLITS = 8
+
+
+def candidates(n_out: int, k: int, silu: bool, m: int, allow_split: bool = False):
+    """(tiles, splits) launch shapes worth timing for one projection."""
+    units = n_out // 16
+    max_u = (3 if m <= 64 else 2) if silu else 4
+    ksteps = k // 32
+    out = []
+    tiles_opts = {(units + u - 1) // u for u in range(1, max_u + 1)}
+    tiles_opts |= {t for t in (256, 512) if t <= units and (units + t - 1) // t <= max_u}
+    for tiles in sorted(tiles_opts):
+        for splits in (1, 2, 3, 4, 6, 8):
+            if splits > 1 and not allow_split:
+                continue
+            if ksteps < splits * 8 or not 48 <= tiles * splits <= 2100:
+                continue
+            out.append((tiles, splits))
+    return out
+
+
+class TsLinearSet:
+    """Fragment-major weights + launch plans of one model."""
+    NAMES = ("qkv", "o", "gate_up", "down", "lm_head")
+
+    def __init__(self, weights, dims):
+        self.W, self.dims = weights, dims
+        self.device = torch.device(weights.device)
+        self._frag: dict = {}
+        self._plans: dict = {}          # q_len -> {name: None | (tiles, splits)}
+        self.tuned: dict = {}           # plan_key -> record of a timing run (for export)
+        d = dims
+        hd = d.local_heads * d.head_dim
+        self.shapes = {                  # name -> (n_out, k, silu)
+            "qkv": ((d.local_heads + 2 * d.local_kv_heads) * d.head_dim, d.hidden_size, False),
+            "o": (d.hidden_size, hd, False),
+            "gate_up": (weights.layers[0].w_down.shape[1], d.hidden_size, True),
+            "down": (d.hidden_size, weights.layers[0].w_down.shape[1], False),
+            "lm_head": (weights.lm_head.shape[0], d.hidden_size, False),
+        }
+        # split-K partials [splits][rows][n_out] fp32: one buffer for the model's life (captured graphs hold it)
+        self._slab = torch.empty(MAX_SPLITS * MAX_ROWS * max(self.shapes[n][0] for n in SPLITTABLE), dtype=torch.float32,
+                                 device=self.device)
+
+    @staticmethod
+    def supported(weights, dims, reduce_fn) -> bool:
+        if (not ENABLED or reduce_fn is not None or torch.device(weights.device).type != "cuda"
+                or weights.dtype != torch.float16):
+            return False
+        inter = weights.layers[0].w_down.shape[1]
+        hd = dims.local_heads * dims.head_dim
+        qkv = (dims.local_heads + 2 * dims.local_kv_heads) * dims.head_dim
+        return (dims.hidden_size % 32 == 0 and inter % 32 == 0 and hd % 32 == 0 and qkv % 16 == 0
+                and weights.lm_head.shape[0] % 16 == 0 and 2 * inter * dims.hidden_size * 2 < (1 << 32)
+                and weights.lm_head.shape[0] * dims.hidden_size * 2 < (1 << 32))
+
+    # ---- weights ------------------------------------------------------------------------------------------
+    def _row_major(self, name, li):
+        if name == "lm_head":
+            return self.W.lm_head
+        lw = self.W.layers[li]
+        return {"qkv": lw.wqkv, "o": lw.wo, "gate_up": lw.w_gate_up, "down": lw.w_down}[name]
+
+    def frag(self, name, li=0):
+        key = (name, 0 if name == "lm_head" else li)
+        t = self._frag.get(key)
+        if t is None:
+            t = get_ops().repack_weight(self._row_major(name, li))
+            self._frag[key] = t
+        return t
+
+    def _images_fit(self, name) -> bool:
+        """A second copy of this projection's weights must leave the device comfortable (70B on one GPU does not)."""
+        n_out, k, silu = self.shapes[name]
+        n_layers = 1 if name == "lm_head" else len(self.W.layers)
+        need = n_layers * (2 if silu else 1) * n_out * k * 2
+        free, _ = torch.cuda.mem_get_info(self.device)
+        return need < 0.5 * free
+
+    # ---- plans --------------------------------------------------------------------------------------------
+    def plan(self, q_len: int) -> dict:
+        p = self._plans.get(q_len)
+        if p is None:
+            p = {}
+            mtp = (q_len + 15) // 16
+            for name in self.NAMES:
+                n_out, k, silu = self.shapes[name]
+                key = plan_key(n_out, k, silu, mtp)
+                rec = shipped_plans().get(key)
+                if rec != "torch" and (name, 0) not in self._frag and not self._images_fit(name):
+                    rec = "torch"
+                if rec is None:
+                    if torch.cuda.is_current_stream_capturing():
+                        rec = "torch"                      # never time inside a capture; the eager warm-ups tune first
+                    else:
+                        rec = self.autotune(name, q_len)
+                p[name] = None if rec == "torch" else (int(rec[0]), int(rec[1]))
+            for name, v in p.items():                       # materialise the weight images outside any capture
+                if v is not None:
+                    for li in range(1 if name == "lm_head" else len(self.W.layers)):
+                        self.frag(name, li)
+            if not torch.cuda.is_current_stream_capturing():
+                self._plans[q_len] = p
+        return p
+
+    @torch.inference_mode()
+    def autotune(self, name: str, q_len: int, reps: int = 16):
+        """Time the kernel's launch shapes and torch's GEMM for one projection at q_len rows, rotating over the
+        layers' weights (32 x 100+ MB: nothing stays in the 256 MiB Infinity Cache).  Returns "torch" or
+        [tiles, splits]; the record lands in self.tuned."""
+        ops = get_ops()
+        n_out, k, silu = self.shapes[name]
+        n_layers = 1 if name == "lm_head" else len(self.W.layers)
+        dev = self.device
+        x = (torch.randn(q_len, k, device=dev) * 0.5).half()
+        xf = ops.repack_rows(x)
+        out = torch.empty((q_len, n_out), dtype=torch.float16, device=dev)
+        act = torch.empty((q_len, n_out), dtype=torch.float16, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def timeit(fn):
+            """GPU time per call: `reps` calls captured into a hipGraph and replayed (an eager launch costs the host
+            7-20 us, more than the small projections take on the GPU)."""
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for i in range(2):
+                    fn(i % n_layers)
+                side.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for i in range(reps):
+                        fn(i % n_layers)
+                g.replay()
+                e0.record(side)
+                g.replay()
+                e1.record(side)
+                e1.synchronize()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            return e0.elapsed_time(e1) * 1e3 / reps
+
+        def torch_fn(li):
+            y = F.linear(x, self._row_major(name, li))
+            if silu:
+                ops.silu_mul(y, act)
+        t_torch = timeit(torch_fn)
+        best, t_best = "torch", t_torch
+        results = {}
+        for tiles, splits in candidates(n_out, k, silu, q_len, allow_split=name in SPLITTABLE):
+            slab = self._slab if splits > 1 else None
+
+            def ts_fn(li, tiles=tiles, splits=splits, slab=slab):
+                ops.linear_ts(xf, self.frag(name, li), q_len, n_out, k, out=out, silu=silu, tiles=tiles, splits=splits,
+                              slab=slab)
+            for li in range(n_layers):
+                self.frag(name, li)
+            t = timeit(ts_fn)
+            results[f"{tiles}x{splits}"] = round(t, 2)
+            if t < t_best * 0.97:                            # prefer torch on a tie: no second weight image needed
+                best, t_best = [tiles, splits], t
+        key = plan_key(n_out, k, silu, (q_len + 15) // 16)
+        self.tuned[key] = dict(choice=best, us=round(t_best, 2), torch_us=round(t_torch, 2), q_len=q_len, ts_us=results)
+        if best == "torch":                                  # drop images that will not be used
+            for li in range(n_layers):
+                self._frag.pop((name, li), None)
+        return best
+
+
+def forward_ts(model, ts: TsLinearSet, x, q_len, pos, storage_ids, dense, tree, kv_cache):
+    """Decoder forward of <= 128 tree tokens on the tall-skinny projections.  x: [q, hidden] embeddings.
+    Returns logits [1, q, V]."""
+    from .Llama_modules import attention_core
+    ops = get_ops()
+    W, dims = model.weights, model.dims
+    eps = dims.rms_norm_eps
+    plan = ts.plan(q_len)
+    dev, dt = x.device, x.dtype
+    hidden = dims.hidden_size
+    n_qkv, _, _ = ts.shapes["qkv"]
+    inter = ts.shapes["down"][1]
+    vocab = ts.shapes["lm_head"][0]
+    fs = ops.frag_shape
+    slab = ts._slab
+
+    def norm_into(pending, weight, want_frag):
+        """Apply the pending branch output (None | ("rows", t) | ("slab", splits)) to the residual stream x,
+        then RMSNorm into a row-major or fragment-major buffer."""
+        out = torch.empty(fs(q_len, hidden) if want_frag else (q_len, hidden), dtype=dt, device=dev)
+        if pending is None:
+            (ops.rmsnorm_frag if want_frag else ops.rmsnorm)(x, weight, out, eps)
+        elif pending[0] == "slab":
+            ops.add_rmsnorm_slabs(slab, pending[1], x, x, weight, out, eps, out_frag=want_frag)
+        elif want_frag:
+            ops.add_rmsnorm_frag(pending[1], x, x, weight, out, eps)
+        else:
+            ops.add_rmsnorm(pending[1], x, x, weight, out, eps)
+        return out
+
+    def project(name, li, a, a_is_frag):
+        """One projection with output to rows or slabs.  Returns the pending record."""
+        p = plan[name]
+        n_out, k, _ = ts.shapes[name]
+        if p is None:
+            return ("rows", F.linear(a, ts._row_major(name, li)))
+        tiles, splits = p
+        if splits > 1:
+            ops.linear_ts(a, ts.frag(name, li), q_len, n_out, k, tiles=tiles, splits=splits, slab=slab)
+            return ("slab", splits)
+        out = torch.empty((q_len, n_out), dtype=dt, device=dev)
+        ops.linear_ts(a, ts.frag(name, li), q_len, n_out, k, out=out, tiles=tiles, splits=1)
+        return ("rows", out)
+
+    pending = None
+    for li, lw in enumerate(W.layers):
+        h = norm_into(pending, lw.ln1, plan["qkv"] is not None)
+        qkv = project("qkv", li, h, plan["qkv"] is not None)[1]
+        attn = attention_core(qkv, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
+                              out_frag=plan["o"] is not None)
+        pending = project("o", li, attn, plan["o"] is not None)
+        h = norm_into(pending, lw.ln2, plan["gate_up"] is not None)
+        down_ts = plan["down"] is not None
+        act = torch.empty(fs(q_len, inter) if down_ts else (q_len, inter), dtype=dt, device=dev)
+        if plan["gate_up"] is not None:
+            tiles, _ = plan["gate_up"]
+            ops.linear_ts(h, ts.frag("gate_up", li), q_len, inter, hidden, out=act, silu=True, out_frag=down_ts, tiles=tiles)
+        else:
+            gu = F.linear(h, lw.w_gate_up)
+            if down_ts:
+                ops.silu_mul_frag(gu, act, q_len, inter)
+            else:
+                ops.silu_mul(gu, act)
+        pending = project("down", li, act, down_ts)
+    h = norm_into(pending, W.norm, plan["lm_head"] is not None)
+    kv_cache.note_written(q_len)
+    if plan["lm_head"] is not None:
+        tiles, _ = plan["lm_head"]
+        logits = torch.empty((q_len, vocab), dtype=dt, device=dev)
+        ops.linear_ts(h, ts.frag("lm_head"), q_len, vocab, hidden, out=logits, tiles=tiles)
+    else:
+        logits = F.linear(h, W.lm_head)
+    return logits.unsqueeze(0)

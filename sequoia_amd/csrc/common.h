@@ -13,6 +13,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define SQ_WAVE 64
 
+// Fragment-major activation image consumed by the tall-skinny linear layer (ts_linear.hip): the 8-element chunk
+// c (columns 8c .. 8c+7) of row r of an [rows][cols] matrix lives at
+// [c / 4][r / 16][(c % 4) * 16 + r % 16][8], mtp = ceil(rows / 16) row tiles.  Returns the element offset.
+__device__ __forceinline__ size_t frag_chunk_offset(size_t row, int c, int mtp) {
+    return ((((size_t)(c >> 2)) * mtp + (row >> 4)) * 64 + (c & 3) * 16 + (row & 15)) * 8;
+}
+
 // error plumbing (host side) ----------------------------------------------------------------
 void sq_set_error(hipError_t e);
 static inline int sq_check_launch() {

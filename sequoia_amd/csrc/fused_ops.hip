@@ -10,10 +10,11 @@
 #define ROW_WAVES (ROW_THREADS / 64)
 
 // x: [rows][hidden] fp16; optional residual add: h = x + res (fp16 add), h written back to res_out.
-template <bool ADD>
+// FRAG: `out` is the fragment-major activation image of the tall-skinny linear layer (frag_chunk_offset, common.h)
+template <bool ADD, bool FRAG>
 __global__ void __launch_bounds__(ROW_THREADS)
 rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ res, half_t* __restrict__ sum_out,
-               const half_t* __restrict__ w, half_t* __restrict__ out, int hidden, float eps) {
+               const half_t* __restrict__ w, half_t* __restrict__ out, int hidden, float eps, int mtp) {
     __shared__ float s_f[ROW_WAVES];
     const size_t row = blockIdx.x;
     const half_t* xr = x + row * hidden;
@@ -44,7 +45,7 @@ rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ res, hal
             const half_t n = (half_t)((float)v[j] * inv);
             o[j] = (half_t)((float)wv[j] * (float)n);
         }
-        *(half8*)(out + row * hidden + c * 8) = o;
+        *(half8*)(out + (FRAG ? frag_chunk_offset(row, c, mtp) : row * hidden + c * 8)) = o;
     }
 }
 
@@ -53,9 +54,21 @@ extern "C" int sq_rmsnorm_f16(const void* x, const void* weight, void* out, int 
     if (!x || !weight || !out || rows < 0 || hidden <= 0) return SQ_EINVAL;
     if (hidden & 7) return SQ_EUNSUPPORTED;
     if (rows == 0) return SQ_OK;
-    hipLaunchKernelGGL((rmsnorm_kernel<false>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((rmsnorm_kernel<false, false>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        (const half_t*)x, (const half_t*)nullptr, (half_t*)nullptr, (const half_t*)weight, (half_t*)out,
-                       hidden, eps);
+                       hidden, eps, 0);
+    return sq_check_launch();
+}
+
+// same, output written fragment-major ([hidden / 32][ceil(rows / 16)][64][8]) for sq_linear_ts_f16
+extern "C" int sq_rmsnorm_frag_f16(const void* x, const void* weight, void* out_frag, int rows, int hidden, float eps,
+                                   void* stream) {
+    if (!x || !weight || !out_frag || rows < 0 || hidden <= 0) return SQ_EINVAL;
+    if (hidden & 31) return SQ_EUNSUPPORTED;
+    if (rows == 0) return SQ_OK;
+    hipLaunchKernelGGL((rmsnorm_kernel<false, true>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       (const half_t*)x, (const half_t*)nullptr, (half_t*)nullptr, (const half_t*)weight,
+                       (half_t*)out_frag, hidden, eps, (rows + 15) / 16);
     return sq_check_launch();
 }
 
@@ -65,15 +78,90 @@ extern "C" int sq_add_rmsnorm_f16(const void* x, const void* residual, void* sum
     if (!x || !residual || !sum_out || !weight || !out || rows < 0 || hidden <= 0) return SQ_EINVAL;
     if (hidden & 7) return SQ_EUNSUPPORTED;
     if (rows == 0) return SQ_OK;
-    hipLaunchKernelGGL((rmsnorm_kernel<true>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((rmsnorm_kernel<true, false>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        (const half_t*)x, (const half_t*)residual, (half_t*)sum_out, (const half_t*)weight,
-                       (half_t*)out, hidden, eps);
+                       (half_t*)out, hidden, eps, 0);
+    return sq_check_launch();
+}
+
+extern "C" int sq_add_rmsnorm_frag_f16(const void* x, const void* residual, void* sum_out, const void* weight,
+                                        void* out_frag, int rows, int hidden, float eps, void* stream) {
+    if (!x || !residual || !sum_out || !weight || !out_frag || rows < 0 || hidden <= 0) return SQ_EINVAL;
+    if (hidden & 31) return SQ_EUNSUPPORTED;
+    if (rows == 0) return SQ_OK;
+    hipLaunchKernelGGL((rmsnorm_kernel<true, true>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       (const half_t*)x, (const half_t*)residual, (half_t*)sum_out, (const half_t*)weight,
+                       (half_t*)out_frag, hidden, eps, (rows + 15) / 16);
+    return sq_check_launch();
+}
+
+// Same as rmsnorm_kernel<true>, with x arriving as `splits` fp32 partial products of a split-K linear layer
+// (sq_linear_ts_f16): x = h(((s0 + s1) + s2) + ...) -- the layer's fp16 output rounding -- then h = x + res.
+// NORM = false stops after the add (the sum feeds a later, separate normalisation).
+template <bool NORM>
+__global__ void __launch_bounds__(ROW_THREADS)
+rmsnorm_slabs_kernel(const float* __restrict__ slab, int splits, size_t split_stride, const half_t* __restrict__ res,
+                     half_t* __restrict__ sum_out, const half_t* __restrict__ w, half_t* __restrict__ out, int hidden,
+                     float eps, int frag_mtp) {
+    __shared__ float s_f[ROW_WAVES];
+    const size_t row = blockIdx.x;
+    const int chunks = hidden >> 3;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < chunks; c += ROW_THREADS) {
+        const float* sp = slab + row * hidden + c * 8;
+        floatx4 a = *(const floatx4*)sp, b = *(const floatx4*)(sp + 4);
+        for (int s = 1; s < splits; ++s) {
+            a += *(const floatx4*)(sp + s * split_stride);
+            b += *(const floatx4*)(sp + s * split_stride + 4);
+        }
+        const half8 r = *(const half8*)(res + row * hidden + c * 8);
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = (half_t)((float)(half_t)a[j] + (float)r[j]);
+            v[4 + j] = (half_t)((float)(half_t)b[j] + (float)r[4 + j]);
+        }
+        *(half8*)(sum_out + row * hidden + c * 8) = v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+    }
+    if (!NORM) return;
+    const float tot = block_sum_f32<ROW_WAVES>(ss, s_f);
+    const float inv = rsqrtf(tot / (float)hidden + eps);
+    for (int c = threadIdx.x; c < chunks; c += ROW_THREADS) {
+        const half8 v = *(const half8*)(sum_out + row * hidden + c * 8);      // this thread's own stores above
+        const half8 wv = *(const half8*)(w + c * 8);
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const half_t n = (half_t)((float)v[j] * inv);
+            o[j] = (half_t)((float)wv[j] * (float)n);
+        }
+        *(half8*)(out + (frag_mtp ? frag_chunk_offset(row, c, frag_mtp) : row * hidden + c * 8)) = o;
+    }
+}
+
+extern "C" int sq_add_rmsnorm_slabs_f16(const void* slab, int splits, const void* residual, const void* weight,
+                                         void* sum_out, void* out, int out_frag, int rows, int hidden, float eps,
+                                         void* stream) {
+    if (!slab || !residual || !sum_out || splits < 1 || rows < 0 || hidden <= 0 || (out && !weight)) return SQ_EINVAL;
+    if ((hidden & 7) || ((uintptr_t)slab & 15) || (out_frag && (hidden & 31))) return SQ_EUNSUPPORTED;
+    if (rows == 0) return SQ_OK;
+    const size_t stride = (size_t)rows * hidden;
+    if (out)
+        hipLaunchKernelGGL((rmsnorm_slabs_kernel<true>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                           (const float*)slab, splits, stride, (const half_t*)residual, (half_t*)sum_out,
+                           (const half_t*)weight, (half_t*)out, hidden, eps, out_frag ? (rows + 15) / 16 : 0);
+    else
+        hipLaunchKernelGGL((rmsnorm_slabs_kernel<false>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                           (const float*)slab, splits, stride, (const half_t*)residual, (half_t*)sum_out,
+                           (const half_t*)nullptr, (half_t*)nullptr, hidden, eps, 0);
     return sq_check_launch();
 }
 
 // gate_up: [rows][2*inter] (gate | up), out: [rows][inter];  out = h(h(silu(gate)) * up)
 __global__ void __launch_bounds__(ROW_THREADS)
-silu_mul_kernel(const half_t* __restrict__ gate_up, half_t* __restrict__ out, int inter) {
+silu_mul_kernel(const half_t* __restrict__ gate_up, half_t* __restrict__ out, int inter, int frag_mtp) {
     const size_t row = blockIdx.y;
     const int c = blockIdx.x * ROW_THREADS + threadIdx.x;
     if (c * 8 >= inter) return;
@@ -86,7 +174,7 @@ silu_mul_kernel(const half_t* __restrict__ gate_up, half_t* __restrict__ out, in
         const half_t s = (half_t)(gf / (1.0f + expf(-gf)));
         o[j] = (half_t)((float)s * (float)uv[j]);
     }
-    *(half8*)(out + row * inter + c * 8) = o;
+    *(half8*)(out + (frag_mtp ? frag_chunk_offset(row, c, frag_mtp) : row * inter + c * 8)) = o;
 }
 
 extern "C" int sq_silu_mul_f16(const void* gate_up, void* out, int rows, int inter, void* stream) {
@@ -95,6 +183,16 @@ extern "C" int sq_silu_mul_f16(const void* gate_up, void* out, int rows, int int
     if (rows == 0) return SQ_OK;
     const int chunks = inter >> 3;
     hipLaunchKernelGGL(silu_mul_kernel, dim3((chunks + ROW_THREADS - 1) / ROW_THREADS, rows), dim3(ROW_THREADS), 0,
-                       (hipStream_t)stream, (const half_t*)gate_up, (half_t*)out, inter);
+                       (hipStream_t)stream, (const half_t*)gate_up, (half_t*)out, inter, 0);
+    return sq_check_launch();
+}
+
+extern "C" int sq_silu_mul_frag_f16(const void* gate_up, void* out_frag, int rows, int inter, void* stream) {
+    if (!gate_up || !out_frag || rows < 0 || inter <= 0) return SQ_EINVAL;
+    if (inter & 31) return SQ_EUNSUPPORTED;
+    if (rows == 0) return SQ_OK;
+    const int chunks = inter >> 3;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((chunks + ROW_THREADS - 1) / ROW_THREADS, rows), dim3(ROW_THREADS), 0,
+                       (hipStream_t)stream, (const half_t*)gate_up, (half_t*)out_frag, inter, (rows + 15) / 16);
     return sq_check_launch();
 }

@@ -33,7 +33,8 @@ struct AttnParams {
     const half_t* q;        // [H][q_len][D]
     const half_t* k;        // [H_kv][M][D]
     const half_t* v;        // [H_kv][M][D]
-    half_t* out;            // [q_len][H*D]
+    half_t* out;            // [q_len][H*D], or its fragment-major image (out_frag_mtp = ceil(q_len / 16) > 0)
+    int out_frag_mtp;
     int q_len, n_heads, h_kv, m, kv_len;
     float scale_log2e;      // scale * log2(e)
     int mask_mode;          // 0 dense additive, 1 implicit tree
@@ -397,7 +398,9 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
         }
         const float inv = denom > 0.f ? 1.0f / denom : 0.f;
         if (q0 + row < P.q_len) {
-            half_t* dst = P.out + (size_t)(q0 + row) * (P.n_heads * D) + head * D + col;
+            const int ocol = head * D + col;
+            half_t* dst = P.out_frag_mtp ? P.out + frag_chunk_offset(q0 + row, ocol >> 3, P.out_frag_mtp) + (ocol & 7)
+                                         : P.out + (size_t)(q0 + row) * (P.n_heads * D) + ocol;
             float res[EPT_O];
 #pragma unroll
             for (int e = 0; e < EPT_O; ++e) {
@@ -434,7 +437,11 @@ extern "C" int sq_tree_attention_f16(const void* q, const void* k_layer, const v
     if (d_ctx) { if (kv_len <= 0) kv_len = 1; if (gt < 1) gt = 1; }
     if (kv_len <= 0 || kv_len > m || n_heads % h_kv) return SQ_EINVAL;
     if (d != 64 && d != 128) return SQ_EUNSUPPORTED;
+    const int out_frag = mask_mode & SQ_ATT_OUT_FRAG;
+    mask_mode &= ~SQ_ATT_OUT_FRAG;
+    if (out_frag && ((n_heads * d) & 31)) return SQ_EUNSUPPORTED;
     AttnParams P;
+    P.out_frag_mtp = out_frag ? (q_len + 15) / 16 : 0;
     P.q = (const half_t*)q; P.k = (const half_t*)k_layer; P.v = (const half_t*)v_layer; P.out = (half_t*)out;
     P.q_len = q_len; P.n_heads = n_heads; P.h_kv = h_kv; P.m = m; P.kv_len = kv_len;
     P.scale_log2e = scale * 1.4426950408889634f;
@@ -478,6 +485,7 @@ extern "C" int sq_rope_tree_attention_f16(const void* qkv, int qkv_stride, void*
     if (d != 64 && d != 128) return SQ_EUNSUPPORTED;
     if (q_len == 0) return SQ_OK;
     AttnParams P;
+    P.out_frag_mtp = 0;
     P.q = nullptr; P.k = (const half_t*)k_layer; P.v = (const half_t*)v_layer; P.out = (half_t*)out;
     P.q_len = q_len; P.n_heads = n_heads; P.h_kv = h_kv; P.m = m; P.kv_len = kv_len;
     P.scale_log2e = scale * 1.4426950408889634f;

@@ -1,0 +1,297 @@
+// Tall-skinny linear layers of the tree forwards: out[M, N] = A[M, K] . W[N, K]^T for M <= 128 rows
+// (M = the nodes of one speculation tree / tree level), fp16 in, fp32 accumulate, fp16 out.
+//
+// The regime: every weight is used by <= 128 rows, so the layer is an HBM stream of W (7B: 13 GB per
+// verify) with a little MFMA work on the side.  The kernel is built as a weight stream first:
+//   * both operands live in HBM in MFMA-fragment order ("fragment-major"): for v_mfma_f32_16x16x32_f16 a lane
+//     (g = lane / 16, r = lane % 16) supplies 8 consecutive k of row r, k = 32 kb + 8 g + (0..7); the image
+//         X_f[tile = row / 16][kb = k / 32][lane][8]            (weights:      tile-major, 1 KB per (tile, kb))
+//         A_f[kb = k / 32][tile = row / 16][lane][8]            (activations:  k-major)
+//     makes every wave-wide operand load one contiguous 1 KB read.  Row-major operands cost this kernel
+//     2-2.5x (measured: 16 rows x 64 B per instruction, rows a power-of-two stride apart: half-used lines and
+//     L2 channel conflicts).  Weights are repacked once at load (sq_repack_linear_weight_f16); activations are
+//     written fragment-major by their producers (RMSNorm, attention, the SwiGLU epilogue below);
+//   * a workgroup owns a contiguous range of 16-column units of the output (balanced partition of N / 16
+//     units over the launch's `tiles` workgroups, <= NT MFMA column tiles each) and ALL M activation rows;
+//     its 4 waves split the workgroup's K range, so every weight byte is loaded by exactly one wave,
+//     straight into the MFMA B-operand registers (no LDS), non-temporal, and each wave streams NT contiguous
+//     runs of HBM;
+//   * HBM latency is covered by depth, not occupancy: each wave keeps a ring of D k-steps of operand
+//     loads in flight (D x (NT + MT) 16-byte loads per lane; 4 waves x D x NT KB of weights per CU);
+//   * the 4 K-partials of a workgroup meet in LDS once ([row][col] fp32 images, one barrier) and are
+//     summed in wave order by the threads that write the output, 16 bytes per lane;
+//   * small-N layers (o_proj, down_proj: too few column tiles to fill 256 CUs) also split K over `splits`
+//     workgroups; each writes its fp32 partial matrix to slab[split][M][N] and the consumer
+//     (sq_add_rmsnorm_slabs_f16: the residual add + RMSNorm that follows both layers) sums them in split
+//     order -- no atomics, no fences, results independent of scheduling;
+//   * epilogues (splits == 1): plain, + residual (fp16 add after the fp16 rounding of the product), or
+//     SwiGLU (W = [gate rows | up rows]; a unit = 16 gate + the matching 16 up rows; writes
+//     h(h(silu(h(g))) * h(u)), the rounding points of LlamaMLP_FI, Engine/Llama_modules.py:271); the output
+//     is row-major or fragment-major (when it feeds the next tall-skinny layer).
+#include "common.h"
+
+#define TS_WAVES 4
+#define TS_THREADS (TS_WAVES * 64)
+#define TS_MAXM 128
+
+struct TsParams {
+    const half_t* a;      // fragment-major activations [K/32][mtp][64][8]
+    const half_t* w;      // fragment-major weights [N/16][K/32][64][8]  (SILU: N = 2 n_out, gate tiles then up tiles)
+    const half_t* res;    // [M][ldo] residual or null (row-major output only)
+    half_t* out;          // [M][ldo] row-major, or fragment-major [n_out/32][mtp][64][8]   (splits == 1)
+    float* slab;          // [splits][M][n_out] fp32                                         (splits > 1)
+    int m, mtp, n_out, k, ldo, splits, tiles, units, out_frag;
+};
+
+template <int MT, int NT, int D, bool SILU>
+__global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P) {
+    extern __shared__ float ts_lds[];                       // 4 waves x [MT*16][LDW] fp32
+    constexpr int LDW = NT * 16 + 4;                         // row stride: 16-byte aligned, 4 rows apart = 16 banks apart
+    constexpr int TPU = SILU ? 2 : 1;                        // MFMA column tiles per 16-column output unit
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: K ranges and loop bounds stay scalar
+    const int r16 = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x % P.tiles, split = blockIdx.x / P.tiles;
+    const int u0 = (int)((long)tile * P.units / P.tiles), u1 = (int)((long)(tile + 1) * P.units / P.tiles);
+    const int nu = u1 - u0;                                  // 16-column units of this workgroup (<= NT / TPU)
+
+    // ---- this wave's K range -----------------------------------------------------------------------------
+    const int ksteps = P.k >> 5;
+    const int parts = P.splits * TS_WAVES;
+    const int per = (ksteps + parts - 1) / parts;
+    const int ks0 = min(ksteps, (split * TS_WAVES + wave) * per), ks1 = min(ksteps, ks0 + per);
+
+    // byte offsets of this lane's operand fragments at k-step 0; column tiles beyond the workgroup's range and
+    // row tiles beyond the activation's alias the last valid one (L1 hits; their products are never stored)
+    uint32_t woff[NT], aoff[MT];
+    const uint32_t w_tile_bytes = (uint32_t)ksteps * 1024u;   // one 16-row weight tile, all of K
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tt = min(t, nu * TPU - 1);
+        const int wtile = u0 + tt / TPU + ((SILU && (tt & 1)) ? P.units : 0);
+        woff[t] = (uint32_t)wtile * w_tile_bytes + (uint32_t)lane * 16u;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) aoff[mt] = (uint32_t)min(mt, P.mtp - 1) * 1024u + (uint32_t)lane * 16u;
+    const uint32_t a_step = (uint32_t)P.mtp * 1024u;
+    const char* wbase = (const char*)P.w;
+    const char* abase = (const char*)P.a;
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    if (ks0 < ks1) {
+        half8 wr[D][NT], ar[D][MT];
+        const int last = ks1 - 1;
+#define TS_LOAD(d, KS)                                                                                 \
+    {                                                                                                  \
+        const uint32_t kw_ = (uint32_t)(KS) << 10, ka_ = (uint32_t)(KS) * a_step;                      \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                 \
+            wr[d][t] = __builtin_nontemporal_load((const half8*)(wbase + (woff[t] + kw_)));            \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ar[d][mt] = *(const half8*)(abase + (aoff[mt] + ka_)); \
+    }
+#define TS_MMA(d)                                                                                      \
+    {                                                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                             \
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[d][mt], wr[d][t], acc[mt][t], 0, 0, 0); \
+    }
+#pragma unroll
+        for (int d = 0; d < D; ++d) TS_LOAD(d, min(ks0 + d, last));
+        const int nfull = (ks1 - ks0) / D, rem = (ks1 - ks0) - nfull * D;
+        int ks = ks0;
+        for (int it = 0; it < nfull; ++it, ks += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                TS_MMA(d);
+                TS_LOAD(d, min(ks + D + d, last));           // refill the stage just consumed (clamped at the end)
+                __builtin_amdgcn_sched_barrier(0);           // keep the stages in ring order (no cross-stage MFMA interleave)
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+            if (d < rem) TS_MMA(d);                          // stages 0 .. rem-1 hold the last steps
+#undef TS_MMA
+#undef TS_LOAD
+    }
+
+    // ---- the 4 wave partials meet in LDS: image[wave][row][col], MFMA C layout row = 16 mt + 4 g + i -----------
+    float* mine = ts_lds + (size_t)wave * (MT * 16) * LDW;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mine[(mt * 16 + g * 4 + i) * LDW + t * 16 + r16] = acc[mt][t][i];
+    __syncthreads();
+
+    // output items: (row, 8-column group); a unit holds 2 groups
+    const int groups = nu * 2;
+    const int items = P.m * groups;
+    for (int it = tid; it < items; it += TS_THREADS) {
+        const int row = it / groups, grp = it % groups;
+        const int unit = grp >> 1, half = grp & 1;
+        const int col = (unit * TPU) * 16 + half * 8;          // LDS column of the main (gate) values
+        float v[8], u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = 0.f; u[j] = 0.f; }
+#pragma unroll
+        for (int wv = 0; wv < TS_WAVES; ++wv) {
+            const float* src = ts_lds + ((size_t)wv * (MT * 16) + row) * LDW + col;
+            const floatx4 x = *(const floatx4*)src, y = *(const floatx4*)(src + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += x[j]; v[4 + j] += y[j]; }
+            if (SILU) {
+                const floatx4 p = *(const floatx4*)(src + 16), q = *(const floatx4*)(src + 20);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { u[j] += p[j]; u[4 + j] += q[j]; }
+            }
+        }
+        const int ocol = (u0 + unit) * 16 + half * 8;
+        if (P.splits > 1) {
+            float* dst = P.slab + ((size_t)split * P.m + row) * P.n_out + ocol;
+            *(floatx4*)dst = floatx4{v[0], v[1], v[2], v[3]};
+            *(floatx4*)(dst + 4) = floatx4{v[4], v[5], v[6], v[7]};
+            continue;
+        }
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            half_t h = (half_t)v[j];
+            if (SILU) {
+                const float gf = (float)h;
+                const half_t sg = (half_t)(gf / (1.0f + expf(-gf)));
+                h = (half_t)((float)sg * (float)(half_t)u[j]);
+            }
+            o[j] = h;
+        }
+        if (P.out_frag) {      // element (row, ocol + j) -> [ocol / 32][row / 16][(ocol / 8 % 4) * 16 + row % 16][j]
+            const size_t foff = (((size_t)(ocol >> 5) * P.mtp + (row >> 4)) * 64 + ((ocol >> 3) & 3) * 16 + (row & 15)) * 8;
+            *(half8*)(P.out + foff) = o;
+            continue;
+        }
+        const size_t off = (size_t)row * P.ldo + ocol;
+        if (!SILU && P.res) {
+            const half8 r = *(const half8*)(P.res + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)o[j] + (float)r[j]);
+        }
+        *(half8*)(P.out + off) = o;
+    }
+}
+
+extern "C" size_t sq_linear_ts_workspace_bytes(int m, int n_out, int splits) {
+    return splits > 1 ? (size_t)splits * m * n_out * sizeof(float) : 0;
+}
+
+template <int MT, int NT, bool SILU>
+static void ts_go(const TsParams& P, hipStream_t st) {
+    constexpr int D = (MT * NT > 24) ? 3 : 4;                // vmcnt holds 63 loads: D (NT + MT) must stay below
+    const size_t lds = (size_t)TS_WAVES * MT * 16 * (NT * 16 + 4) * sizeof(float);
+    auto kern = ts_linear_kernel<MT, NT, D, SILU>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    hipLaunchKernelGGL(kern, dim3(P.tiles * P.splits), dim3(TS_THREADS), lds, st, P);
+}
+
+template <int MT>
+static int ts_dispatch(const TsParams& P, int silu, int nt, hipStream_t st) {
+    if (silu) {
+        if (nt <= 2) ts_go<MT, 2, true>(P, st);
+        else if (nt <= 4) ts_go<MT, 4, true>(P, st);
+        else if (nt <= 6 && MT <= 4) ts_go<MT, (MT <= 4 ? 6 : 4), true>(P, st);
+        else return SQ_EUNSUPPORTED;
+        return SQ_OK;
+    }
+    if (nt <= 2) ts_go<MT, 2, false>(P, st);
+    else if (nt <= 3) ts_go<MT, 3, false>(P, st);
+    else if (nt <= 4) ts_go<MT, 4, false>(P, st);
+    else return SQ_EUNSUPPORTED;
+    return SQ_OK;
+}
+
+extern "C" int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const void* res, void* out, int ldo, int out_frag,
+                                int m, int n_out, int k, int silu, int tiles, int splits, void* slab, size_t slab_bytes,
+                                void* stream) {
+    if (!a_frag || !w_frag || m <= 0 || n_out <= 0 || k <= 0 || splits < 1 || tiles < 1) return SQ_EINVAL;
+    if (splits == 1 && (!out || (!out_frag && ldo < n_out))) return SQ_EINVAL;
+    if (m > TS_MAXM || (k & 31) || (n_out & 15) || (ldo & 7) || ((uintptr_t)a_frag & 15) || ((uintptr_t)w_frag & 15) ||
+        ((uintptr_t)out & 15) || (res && ((uintptr_t)res & 15)) || (size_t)(silu ? 2 : 1) * n_out * k * 2 >= (1ull << 32))
+        return SQ_EUNSUPPORTED;
+    if ((silu && res) || (out_frag && (res || (n_out & 31)))) return SQ_EUNSUPPORTED;
+    TsParams P;
+    P.a = (const half_t*)a_frag; P.w = (const half_t*)w_frag; P.res = (const half_t*)res; P.out = (half_t*)out;
+    P.slab = (float*)slab;
+    P.m = m; P.mtp = (m + 15) / 16; P.n_out = n_out; P.k = k; P.ldo = ldo; P.splits = splits; P.out_frag = out_frag;
+    P.units = n_out / 16;
+    P.tiles = tiles > P.units ? P.units : tiles;
+    if (splits > 1) {
+        if (silu || res || out_frag) return SQ_EUNSUPPORTED;   // the slab consumer applies the epilogue
+        if (!slab || slab_bytes < (size_t)splits * m * n_out * sizeof(float) || ((uintptr_t)slab & 15)) return SQ_EINVAL;
+        if ((k >> 5) < splits * TS_WAVES) return SQ_EUNSUPPORTED;
+    }
+    const int max_units = (P.units + P.tiles - 1) / P.tiles;
+    const int nt = max_units * (silu ? 2 : 1);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const int mt = P.mtp;                                    // row tiles; 5 and 7 run on the 6 / 8 builds (tiles alias)
+    if (mt <= 1) rc = ts_dispatch<1>(P, silu, nt, st);
+    else if (mt == 2) rc = ts_dispatch<2>(P, silu, nt, st);
+    else if (mt == 3) rc = ts_dispatch<3>(P, silu, nt, st);
+    else if (mt == 4) rc = ts_dispatch<4>(P, silu, nt, st);
+    else if (mt <= 6) rc = ts_dispatch<6>(P, silu, nt, st);
+    else rc = ts_dispatch<8>(P, silu, nt, st);
+    if (rc != SQ_OK) return rc;
+    return sq_check_launch();
+}
+
+// ---- fragment-major repacks ----------------------------------------------------------------------------------
+// weights: w [n][k] row-major -> w_f[n / 16][k / 32][lane = (k / 8 % 4) * 16 + n % 16][8]   (once, at load)
+__global__ void __launch_bounds__(256) repack_weight_kernel(const half_t* __restrict__ w, half_t* __restrict__ wf, int n, int k) {
+    const size_t chunk = (size_t)blockIdx.x * 256 + threadIdx.x;        // one 16-byte chunk of the OUTPUT image
+    const size_t total = (size_t)n * k / 8;
+    if (chunk >= total) return;
+    const int ksteps = k >> 5;
+    const int lane = (int)(chunk & 63);
+    const size_t blk = chunk >> 6;
+    const int kb = (int)(blk % ksteps), tile = (int)(blk / ksteps);
+    const int row = tile * 16 + (lane & 15), col = kb * 32 + (lane >> 4) * 8;
+    *(half8*)(wf + chunk * 8) = *(const half8*)(w + (size_t)row * k + col);
+}
+
+extern "C" int sq_repack_linear_weight_f16(const void* w, void* w_frag, int n, int k, void* stream) {
+    if (!w || !w_frag || n <= 0 || k <= 0) return SQ_EINVAL;
+    if ((n & 15) || (k & 31) || w == w_frag) return SQ_EUNSUPPORTED;
+    const size_t chunks = (size_t)n * k / 8;
+    hipLaunchKernelGGL(repack_weight_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)w, (half_t*)w_frag, n, k);
+    return sq_check_launch();
+}
+
+// activations: x [m][ldx] row-major -> x_f[k / 32][ceil(m / 16)][lane = (k / 8 % 4) * 16 + m % 16][8]; rows beyond m
+// are zero.  (The production producers write this image directly; this entry serves callers that hold row-major data.)
+__global__ void __launch_bounds__(256) repack_rows_kernel(const half_t* __restrict__ x, half_t* __restrict__ xf, int m, int k, int ldx) {
+    const int mtp = (m + 15) >> 4;
+    const size_t chunk = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)mtp * 16 * k / 8;
+    if (chunk >= total) return;
+    const int lane = (int)(chunk & 63);
+    const size_t blk = chunk >> 6;
+    const int mt = (int)(blk % mtp), kb = (int)(blk / mtp);
+    const int row = mt * 16 + (lane & 15), col = kb * 32 + (lane >> 4) * 8;
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < m) v = *(const half8*)(x + (size_t)row * ldx + col);
+    *(half8*)(xf + chunk * 8) = v;
+}
+
+extern "C" int sq_repack_rows_frag_f16(const void* x, int ldx, void* x_frag, int m, int k, void* stream) {
+    if (!x || !x_frag || m <= 0 || k <= 0 || ldx < k) return SQ_EINVAL;
+    if ((k & 31) || (ldx & 7) || x == x_frag) return SQ_EUNSUPPORTED;
+    const size_t chunks = (size_t)((m + 15) / 16) * 16 * k / 8;
+    hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, (half_t*)x_frag, m, k, ldx);
+    return sq_check_launch();
+}

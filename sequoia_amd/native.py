@@ -17,6 +17,7 @@ SQ_MAX_TOPK = 128
 SQ_RESULT_INTS = 64
 SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_BONUS, SQ_RES_TERMINAL = 0, 1, 2, 3
 SQ_RES_REASON, SQ_RES_GT, SQ_RES_LAST_NODE, SQ_RES_SLOTS = 4, 5, 6, 8
+SQ_ATT_OUT_FRAG = 0x100
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
@@ -46,6 +47,14 @@ PROTOTYPES = {
     "sq_silu_mul_f16": (_i, [_vp, _vp, _i, _i, _vp]),
     "sq_linear_skinny_f16": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_add_rmsnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "sq_linear_ts_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "sq_linear_ts_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp]),
+    "sq_repack_linear_weight_f16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sq_repack_rows_frag_f16": (_i, [_vp, _i, _vp, _i, _i, _vp]),
+    "sq_add_rmsnorm_slabs_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "sq_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "sq_add_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "sq_silu_mul_frag_f16": (_i, [_vp, _vp, _i, _i, _vp]),
 }
 
 _lib = None

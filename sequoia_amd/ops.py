@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 
 from . import native
-from .native import check
+from .native import SQ_ATT_OUT_FRAG, check
 
 
 def _ptr(t):
@@ -104,8 +104,10 @@ class HipOps:
                                     self._stream()), "sq_store_i32")
 
     def tree_attention(self, q, k_layer, v_layer, out, kv_len, scale, dense_mask=None, q_slot0=0, gt=0, n_tree=0,
-                       bitmask=None, ctx=None):
-        """q: [H, q_len, D]; k/v_layer: [H_kv, M, D]; out: [q_len, H*D]."""
+                       bitmask=None, ctx=None, out_frag=False):
+        """q: [H, q_len, D]; k/v_layer: [H_kv, M, D]; out: [q_len, H*D], or (out_frag) its fragment-major image
+        [H*D/32, ceil(q_len/16), 64, 8] for linear_ts."""
+        frag_flag = SQ_ATT_OUT_FRAG if out_frag else 0
         _need(q, torch.float16, "q"); _need(k_layer, torch.float16, "k_layer"); _need(v_layer, torch.float16, "v_layer")
         _need(out, torch.float16, "out")
         n_heads, q_len, d = q.shape
@@ -115,7 +117,7 @@ class HipOps:
             dm = dense_mask.reshape(dense_mask.shape[-2], dense_mask.shape[-1]) if dense_mask.dim() != 2 else dense_mask
             assert dm.stride(1) == 1 and dm.shape[0] == q_len and dm.shape[1] >= kv_len
             rc = self.lib.sq_tree_attention_f16(q.data_ptr(), k_layer.data_ptr(), v_layer.data_ptr(), out.data_ptr(),
-                                                q_len, n_heads, h_kv, d, m, kv_len, scale, 0, dm.data_ptr(),
+                                                q_len, n_heads, h_kv, d, m, kv_len, scale, 0 | frag_flag, dm.data_ptr(),
                                                 dm.stride(0), 0, 1, 1, None, 0, None, self._stream())
         else:
             words = 0
@@ -123,7 +125,7 @@ class HipOps:
                 _need(bitmask, torch.int64, "bitmask")
                 words = bitmask.shape[1]
             rc = self.lib.sq_tree_attention_f16(q.data_ptr(), k_layer.data_ptr(), v_layer.data_ptr(), out.data_ptr(),
-                                                q_len, n_heads, h_kv, d, m, kv_len, scale, 1, None, 0, q_slot0, gt,
+                                                q_len, n_heads, h_kv, d, m, kv_len, scale, 1 | frag_flag, None, 0, q_slot0, gt,
                                                 n_tree, _ptr(bitmask), words, _ptr(ctx), self._stream())
         check(rc, "sq_tree_attention_f16")
         return out
@@ -243,6 +245,92 @@ class HipOps:
                                             _ptr(res_out), out.data_ptr(), out.stride(0), m, n, k, 1 if silu else 0,
                                             self._stream()), "sq_linear_skinny_f16")
         return out
+
+    # ---- tall-skinny linear layers (fragment-major operands) -----------------------------------
+    @staticmethod
+    def frag_shape(rows, cols):
+        """Shape of the fragment-major image of a [rows, cols] activation."""
+        return (cols // 32, (rows + 15) // 16, 64, 8)
+
+    def repack_weight(self, w):
+        """nn.Linear weight [n, k] -> fragment-major image [n/16, k/32, 64, 8] (new tensor)."""
+        _need(w, torch.float16, "w")
+        n, k = w.shape
+        out = torch.empty((n // 16, k // 32, 64, 8), dtype=w.dtype, device=w.device)
+        check(self.lib.sq_repack_linear_weight_f16(w.data_ptr(), out.data_ptr(), n, k, self._stream()),
+              "sq_repack_linear_weight_f16")
+        return out
+
+    def repack_rows(self, x):
+        """Row-major activations [m, k] -> fragment-major image [k/32, ceil(m/16), 64, 8]."""
+        _need(x, torch.float16, "x", contiguous=False)
+        assert x.dim() == 2 and x.stride(1) == 1
+        m, k = x.shape
+        out = torch.empty(self.frag_shape(m, k), dtype=x.dtype, device=x.device)
+        check(self.lib.sq_repack_rows_frag_f16(x.data_ptr(), x.stride(0), out.data_ptr(), m, k, self._stream()),
+              "sq_repack_rows_frag_f16")
+        return out
+
+    def linear_ts_workspace(self, m, n_out, splits, device):
+        nbytes = int(self.lib.sq_linear_ts_workspace_bytes(m, n_out, splits))
+        return torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=device)
+
+    def linear_ts(self, a_frag, w_frag, m, n_out, k, out=None, res=None, silu=False, out_frag=False, tiles=256, splits=1,
+                  slab=None):
+        """out[m, n_out] = a . w^T on fragment-major operands (m <= 128).  splits > 1: fp32 partials go to `slab`
+        ([splits, m, n_out]) for add_rmsnorm_slabs; otherwise `out` is row-major [m, n_out] or (out_frag) the
+        fragment-major image of the next layer's input."""
+        _need(a_frag, torch.float16, "a_frag"); _need(w_frag, torch.float16, "w_frag")
+        assert a_frag.numel() >= ((m + 15) // 16) * 16 * k and w_frag.numel() == (2 if silu else 1) * n_out * k
+        ldo = 0
+        if splits == 1:
+            _need(out, torch.float16, "out", contiguous=out_frag)
+            ldo = n_out if out_frag else out.stride(0)
+            assert out.numel() >= (((m + 15) // 16) * 16 * n_out if out_frag else m * n_out)
+        else:
+            _need(slab, torch.float32, "slab")
+        if res is not None:
+            _need(res, torch.float16, "res", contiguous=False)
+            assert res.stride(0) == ldo
+        check(self.lib.sq_linear_ts_f16(a_frag.data_ptr(), w_frag.data_ptr(), _ptr(res), _ptr(out), ldo,
+                                        1 if out_frag else 0, m, n_out, k, 1 if silu else 0, int(tiles), int(splits),
+                                        _ptr(slab), slab.numel() * 4 if slab is not None else 0, self._stream()),
+              "sq_linear_ts_f16")
+        return slab if splits > 1 else out
+
+    def add_rmsnorm_slabs(self, slab, splits, residual, sum_out, weight, out, eps, out_frag=False):
+        """x = h(sum of the split-K partials); sum_out = x + residual; out = RMSNorm(sum_out) * weight
+        (out None: add only)."""
+        _need(slab, torch.float32, "slab"); _need(residual, torch.float16, "residual"); _need(sum_out, torch.float16, "sum_out")
+        rows, hidden = residual.shape
+        if out is not None:
+            _need(out, torch.float16, "out"); _need(weight, torch.float16, "weight")
+        check(self.lib.sq_add_rmsnorm_slabs_f16(slab.data_ptr(), int(splits), residual.data_ptr(), _ptr(weight),
+                                                sum_out.data_ptr(), _ptr(out), 1 if out_frag else 0, rows, hidden,
+                                                float(eps), self._stream()), "sq_add_rmsnorm_slabs_f16")
+        return out
+
+    def rmsnorm_frag(self, x, weight, out_frag, eps):
+        _need(x, torch.float16, "x"); _need(weight, torch.float16, "weight"); _need(out_frag, torch.float16, "out_frag")
+        hidden = x.shape[-1]
+        check(self.lib.sq_rmsnorm_frag_f16(x.data_ptr(), weight.data_ptr(), out_frag.data_ptr(), x.numel() // hidden, hidden,
+                                           float(eps), self._stream()), "sq_rmsnorm_frag_f16")
+        return out_frag
+
+    def add_rmsnorm_frag(self, x, residual, sum_out, weight, out_frag, eps):
+        for t, n in ((x, "x"), (residual, "residual"), (sum_out, "sum_out"), (weight, "weight"), (out_frag, "out_frag")):
+            _need(t, torch.float16, n)
+        hidden = x.shape[-1]
+        check(self.lib.sq_add_rmsnorm_frag_f16(x.data_ptr(), residual.data_ptr(), sum_out.data_ptr(), weight.data_ptr(),
+                                               out_frag.data_ptr(), x.numel() // hidden, hidden, float(eps),
+                                               self._stream()), "sq_add_rmsnorm_frag_f16")
+        return out_frag
+
+    def silu_mul_frag(self, gate_up, out_frag, rows, inter):
+        _need(gate_up, torch.float16, "gate_up"); _need(out_frag, torch.float16, "out_frag")
+        check(self.lib.sq_silu_mul_frag_f16(gate_up.data_ptr(), out_frag.data_ptr(), rows, inter, self._stream()),
+              "sq_silu_mul_frag_f16")
+        return out_frag
 
     def silu_mul(self, gate_up, out):
         _need(gate_up, torch.float16, "gate_up"); _need(out, torch.float16, "out")

@@ -40,7 +40,9 @@ def test_host_helper_bitmask_matches_growmap_masks():
                                                  g.child_ids.ctypes.data if g.size > 1 else None, g.size,
                                                  out.ctypes.data, out.shape[1])
         assert rc == 0 and np.array_equal(out, g.bitmask), fn
-        chk = rec["check"]
+        chk = rec.get("check")
+        if chk is None:          # growmaps searched here (sequoia_amd.tree_search) carry no reference record
+            continue
         assert g.roots == chk["roots"] and g.branches == chk["branches"] and g.depth.tolist() == chk["depth"], fn
         assert hashlib.sha256(g.dense_mask().tobytes()).hexdigest() == chk["mask_sha"], fn
         ref = g.to_reference_dict()
