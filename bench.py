@@ -175,7 +175,7 @@ def cpu_baseline(cfg, n_steps=1, pair="calibrated"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="B", choices=sorted(MODELS))
     ap.add_argument("--pair", default="calibrated", choices=["calibrated", "random"])
@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--growmap", default=None, help="override the config's growmap: bundled name or path (.json / reference .pt)")
     ap.add_argument("--no-autoregressive", action="store_true", help="skip the target-only baseline (simulation_baseline)")
+    ap.add_argument("--no-tuned-growmap", action="store_true",
+                    help="skip the second timed loop on the growmap searched for this GPU (config B only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -251,6 +253,19 @@ def main():
                     time_per_step_us=per_step[dom] * 1e6)
         kernels = {k: dict(avg_us=v["seconds"] * 1e6, gbps=v["bytes"] / v["seconds"] / 1e9,
                            per_step_us=per_step[k] * 1e6) for k, v in kr.items()}
+        tuned = None
+        tuned_name = "MI355X-synthetic-68m-7b-stochastic"
+        if not args.no_tuned_growmap and world == 1 and args.config == "B" and not args.growmap and args.pair == "calibrated":
+            # the same loop on the growmap sequoia_amd.growmap_tuning searched for this GPU and this (synthetic)
+            # model pair -- the headline `value` stays on the growmap BASELINE.json names
+            from sequoia_amd.growmap import GrowMap
+            gm2 = GrowMap.load(tuned_name)
+            draft.clear_kv(); target.clear_kv()
+            loop2 = Loop(cfg, draft, target, gm2, device, prompts, use_graphs=not args.no_graphs)
+            loop2.run_steps(args.warmup)
+            s2, t2, k2 = loop2.run_steps(args.steps)
+            tuned = dict(growmap=tuned_name, nodes=gm2.size, value=t2 / s2, unit="tokens/s", ms_per_step=s2 / k2 * 1e3,
+                         mean_accepted_len=t2 / k2, steps=k2)
         autoreg = None
         if not args.no_autoregressive and world == 1:
             # the reference's own comparison point (tests/testbed.py:99-143): the target alone, 1 token / forward
@@ -276,7 +291,8 @@ def main():
                                 gemm="torch TunableOp (hipBLASLt/rocBLAS solution picked per shape)" if gemm_tuned
                                 else "torch default"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs,
-                    roofline=roof, kernels=kernels, autoregressive_baseline=autoreg, cpu_baseline=cpu)
+                    roofline=roof, kernels=kernels, mi355x_growmap=tuned, autoregressive_baseline=autoreg,
+                    cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

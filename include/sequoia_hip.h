@@ -227,18 +227,6 @@ int sq_silu_mul_frag_f16(const void* gate_up, void* out_frag, int rows, int inte
  * gate_up: fp16 [rows][2*inter] packed gate | up (one fused GEMM); out: fp16 [rows][inter].  */
 int sq_silu_mul_f16(const void* gate_up, void* out, int rows, int inter, void* stream);
 
-/* Skinny linear layer for the draft forward (m <= 64 rows), nn.Linear semantics out = f(a) . w^T with
- * fp32 accumulation and fp16 output, and the surrounding row-wise ops fused in:
- *   ln_w != NULL    : a row is first RMS-normalised, h(ln_w * h(x * rsqrt(mean(x^2) + eps)))
- *                     (Engine/Llama_modules.py:282-288); res_in != NULL additionally makes x = a + res_in
- *                     (fp16 add) and writes that sum to sum_out (must not alias a / res_in);
- *   silu != 0       : w holds gate rows [0, n) and up rows [n, 2n); out = h(h(silu(g)) * u)  (:271);
- *   res_out != NULL : out = h(acc) + res_out (fp16 add; out may alias res_out)               (:341-346).
- * a: [m][lda], w: [n or 2n][k] row-major (nn.Linear.weight), out: [m][ldo]; k % 128 == 0.            */
-int sq_linear_skinny_f16(const void* a, int lda, const void* res_in, void* sum_out, const void* ln_w,
-                         float eps, const void* w, const void* res_out, void* out, int ldo,
-                         int m, int n, int k, int silu, void* stream);
-
 /* Fragment-major operand images of the tall-skinny linear layer (MFMA 16x16x32 operand order: lane =
  * (k / 8 % 4) * 16 + row % 16 holds 8 consecutive k of its row, so every wave-wide operand load is 1 KB contiguous):
  *   weights      w_f[n / 16][k / 32][lane][8]   <- w [n][k] row-major (nn.Linear.weight), once at load;

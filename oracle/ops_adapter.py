@@ -140,24 +140,6 @@ class OracleOps:
         sum_out.copy_(torch.from_numpy(s))
         return self.rmsnorm(sum_out, weight, out, eps)
 
-    SKINNY_MAX_M = 64
-
-    def linear_skinny(self, a, w, out, ln_w=None, eps=1e-6, silu=False, res_out=None):
-        x = a
-        if ln_w is not None:
-            x = torch.empty_like(a.contiguous())
-            self.rmsnorm(a.contiguous(), ln_w, x, eps)
-        y = torch.nn.functional.linear(x, w)                 # fp16 in/out, fp32 accumulation inside torch
-        if silu:
-            n = out.shape[1]
-            tmp = torch.empty((a.shape[0], n), dtype=a.dtype)
-            self.silu_mul(y.contiguous(), tmp)
-            y = tmp
-        if res_out is not None:
-            y = torch.from_numpy(O.h(O.f(_np(y)) + O.f(_np(res_out))))
-        out.copy_(y)
-        return out
-
     def silu_mul(self, gate_up, out):
         inter = out.shape[-1]
         g = O.f(_np(gate_up)[:, :inter])

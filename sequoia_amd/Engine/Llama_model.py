@@ -269,10 +269,6 @@ class _LlamaForCausalLM:
         self.dtype, self.device = weights.dtype, weights.device
         self.cos, self.sin = rope_tables(self.dims.head_dim, self.dims.max_position_embeddings, self.dims.rope_theta,
                                          self.device, self.dtype)
-        # fused skinny projections for tree levels: correct (tests) but measured slower than hipBLASLt +
-        # glue launches on MI355X (9.4 vs 4.7 us for the 68m qkv projection) -> opt-in
-        self.use_skinny = os.environ.get("SEQUOIA_SKINNY", "0") == "1"
-        self.skinny_max_hidden = int(os.environ.get("SEQUOIA_SKINNY_MAX_HIDDEN", "1024"))
         # tall-skinny projections for tree forwards (<= 128 rows): fragment-major weight stream, Engine/ts_linear.py
         self.ts = TsLinearSet(weights, self.dims) if TsLinearSet.supported(weights, self.dims, reduce_fn) else None
         self.reduce_fn = reduce_fn                  # TP all-reduce hook (None on one GPU)
@@ -312,8 +308,6 @@ class _LlamaForCausalLM:
         x = F.embedding(input_ids[0], W.embed)                      # [q, hidden]
         if self.ts is not None and q_len <= TS_MAX_ROWS:
             return forward_ts(self, self.ts, x, q_len, pos, storage_ids, dense, tree, kv_cache)
-        if self._skinny_ok(q_len, ops):
-            return self._forward_skinny(x, q_len, pos, storage_ids, dense, tree, kv_cache, ops)
         hbuf = torch.empty_like(x)
         pending = None                                               # branch output not yet added to x
         for li, lw in enumerate(W.layers):
@@ -333,34 +327,6 @@ class _LlamaForCausalLM:
         logits = F.linear(hbuf, W.lm_head)
         if self.gather_logits_fn is not None:
             logits = self.gather_logits_fn(logits)
-        return logits.unsqueeze(0)
-
-    def _skinny_ok(self, q_len, ops) -> bool:
-        d = self.dims
-        # draft-class models only (weights of a layer fit the caches; hipBLASLt wins on the 7B+ shapes)
-        return (self.use_skinny and self.reduce_fn is None and hasattr(ops, "linear_skinny")
-                and d.hidden_size <= self.skinny_max_hidden
-                and q_len <= ops.SKINNY_MAX_M and d.hidden_size % 128 == 0 and d.intermediate_size % 128 == 0
-                and (d.local_heads * d.head_dim) % 128 == 0)
-
-    def _forward_skinny(self, x, q_len, pos, storage_ids, dense, tree, kv_cache, ops):
-        """Forward of a tree level (<= 64 tokens): every projection is one sq_linear_skinny_f16 launch with
-        the RMSNorm / SiLU*up / residual add fused in (6 launches per layer instead of 9, and GEMV-shaped
-        work streamed straight into MFMA fragments).  Same fp16 rounding points as the general path."""
-        W, dims = self.weights, self.dims
-        eps = dims.rms_norm_eps
-        dev, dt = x.device, x.dtype
-        qkv = torch.empty((q_len, W.layers[0].wqkv.shape[0]), dtype=dt, device=dev)
-        act = torch.empty((q_len, W.layers[0].w_down.shape[1]), dtype=dt, device=dev)
-        for li, lw in enumerate(W.layers):
-            ops.linear_skinny(x, lw.wqkv, qkv, ln_w=lw.ln1, eps=eps)
-            attn = attention_core(qkv, li, dims, kv_cache, self.cos, self.sin, pos, storage_ids, dense, tree)
-            ops.linear_skinny(attn, lw.wo, x, res_out=x)                       # x += o_proj(attn)
-            ops.linear_skinny(x, lw.w_gate_up, act, ln_w=lw.ln2, eps=eps, silu=True)
-            ops.linear_skinny(act, lw.w_down, x, res_out=x)                    # x += down(silu(gate) * up)
-        kv_cache.note_written(q_len)
-        logits = torch.empty((q_len, W.lm_head.shape[0]), dtype=dt, device=dev)
-        ops.linear_skinny(x, W.lm_head, logits, ln_w=W.norm, eps=eps)
         return logits.unsqueeze(0)
 
     __call__ = forward

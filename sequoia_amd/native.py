@@ -45,7 +45,6 @@ PROTOTYPES = {
     "sq_verify_greedy_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sq_rmsnorm_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_silu_mul_f16": (_i, [_vp, _vp, _i, _i, _vp]),
-    "sq_linear_skinny_f16": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_add_rmsnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_linear_ts_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "sq_linear_ts_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp]),

@@ -226,26 +226,6 @@ class HipOps:
               "sq_add_rmsnorm_f16")
         return out
 
-    SKINNY_MAX_M = 64
-
-    def linear_skinny(self, a, w, out, ln_w=None, eps=1e-6, silu=False, res_out=None):
-        """out[m, n] = f(a)[m, k] . w^T (m <= 64) with optional RMSNorm prologue (ln_w), SiLU(gate)*up
-        epilogue (w = [2n, k]) or residual-add epilogue (res_out; may alias out)."""
-        _need(a, torch.float16, "a", contiguous=False); _need(w, torch.float16, "w"); _need(out, torch.float16, "out", contiguous=False)
-        assert a.dim() == 2 and out.dim() == 2 and a.stride(1) == 1 and out.stride(1) == 1
-        m, k = a.shape
-        n = out.shape[1]
-        assert w.shape[1] == k and w.shape[0] == (2 * n if silu else n)
-        if ln_w is not None:
-            _need(ln_w, torch.float16, "ln_w")
-        if res_out is not None:
-            _need(res_out, torch.float16, "res_out", contiguous=False)
-            assert res_out.stride(0) == out.stride(0)
-        check(self.lib.sq_linear_skinny_f16(a.data_ptr(), a.stride(0), None, None, _ptr(ln_w), float(eps), w.data_ptr(),
-                                            _ptr(res_out), out.data_ptr(), out.stride(0), m, n, k, 1 if silu else 0,
-                                            self._stream()), "sq_linear_skinny_f16")
-        return out
-
     # ---- tall-skinny linear layers (fragment-major operands) -----------------------------------
     @staticmethod
     def frag_shape(rows, cols):

@@ -107,9 +107,10 @@ def test_dense_mask_signature_matches_tree_context():
         target.inference(input_ids=ids, storage_ids=sid, position_ids=pos, attn_mask=mask[None, None, :, :-1])
 
 
-def test_skinny_draft_forward_matches_general_path():
-    """68m draft architecture: the fused skinny forward (q <= 64) and the hipBLASLt + glue forward give
-    the same logits up to accumulation order (few fp16 ulps) and the same KV cache rows."""
+def test_tall_skinny_draft_forward_matches_general_path():
+    """68m draft architecture: a tree level on the tall-skinny projections (Engine/ts_linear.py) and on the
+    hipBLASLt + glue forward give the same logits up to accumulation order (few fp16 ulps) and the same KV
+    cache rows."""
     from sequoia_amd.Engine.Engine import GraphInferenceEngine
     from sequoia_amd.Engine.Llama_modules import TreeContext
     from sequoia_amd.growmap import GrowMap
@@ -121,8 +122,11 @@ def test_skinny_draft_forward_matches_general_path():
     torch.manual_seed(0)
     ids = torch.randint(3, 32000, (1, 160), device=DEV)
     outs, caches = [], []
+    model = eng.engine.model
+    ts = model.ts
+    assert ts is not None
     for use in (True, False):
-        eng.engine.model.use_skinny = use
+        model.ts = ts if use else None
         eng.clear_kv()
         pos = torch.arange(160, device=DEV)
         # prefill 126 tokens (general path in both runs), then a 34-token tree level
@@ -132,6 +136,8 @@ def test_skinny_draft_forward_matches_general_path():
                            attn_mask=None, tree=TreeContext(126, 126, g.size, bm, 160))
         outs.append(lv.float())
         caches.append(eng.engine.kv_cache.k_cache[:, :, :, :160].float().clone())
+    model.ts = ts
+    assert any(v is not None for v in ts.plan(34).values())
     assert (outs[0] - outs[1]).abs().max() < 6e-2          # logits of magnitude ~10: a few fp16 ulps
     assert (outs[0].argmax(-1) == outs[1].argmax(-1)).float().mean() > 0.9
     assert (caches[0] - caches[1]).abs().max() < 2e-2

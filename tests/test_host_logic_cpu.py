@@ -82,3 +82,30 @@ def test_product_path_refuses_cpu_tensors():
     x = torch.zeros(4, 8, dtype=torch.float16)
     with pytest.raises(native.SequoiaNativeError):
         o.rmsnorm(x, torch.ones(8, dtype=torch.float16), torch.empty_like(x), 1e-6)
+
+
+def test_last_step_before_max_length_completes_and_the_next_is_refused(oracle_ops):
+    """A prompt that leaves room for exactly one tree: verify() must finish the step (the caller's loop ends on
+    its own length test, tests/testbed.py:80); only a further speculation step is an error (README.md:47)."""
+    from conftest import load_trace
+    from helpers import build_engines, make_tree
+    z, meta = load_trace("B_seq128")
+    draft, target = build_engines(z, meta, "cpu")
+    n = len(meta["successors"])
+    M = meta["M"]
+    import numpy as np
+    z2 = dict(z)
+    rng = np.random.default_rng(0)
+    z2["prompt"] = rng.integers(3, meta["vocab"], M - n + 1).astype(np.int64)
+
+    class Z(dict):
+        files = list(z.files)
+    zz = Z(z2)
+    tree = make_tree(zz, meta, draft, target, "cpu")
+    tree.construct_grow_map()
+    valid, a, _, terminal = tree.verify()
+    assert valid.shape[0] >= M - n + 1 + (0 if terminal else 1)
+    if not terminal:
+        assert tree._no_room is not None
+        with pytest.raises(ValueError):
+            tree.construct_grow_map()

@@ -131,20 +131,5 @@ if what in ("glue", "all"):
     out["kv_compact_7b_4rows"] = dict(us=round(timeit(lambda: ops.kv_compact(kc7, vc7, sl, None, 4, 160, 0)), 2))
     e = torch.empty(4, dtype=torch.int32, device=dev)
     out["store_i32(launch floor)"] = dict(us=round(timeit(lambda: ops.store_i32(e, [1, 2, 3])), 2))
-if what in ("skinny", "all"):
-    import torch.nn.functional as F
-    for m in (34, 1):
-        x = torch.randn(m, 768, device=dev).half(); ln = torch.ones(768, device=dev).half()
-        xa = torch.randn(m, 3072, device=dev).half()
-        for name, (n, k, kw) in {"qkv_norm": (2304, 768, dict(ln=True)), "o_res": (768, 768, dict(res=True)),
-                                 "gateup_norm_silu": (3072, 768, dict(ln=True, silu=True)), "down_res": (768, 3072, dict(res=True)),
-                                 "lm_head_norm": (32000, 768, dict(ln=True))}.items():
-            a = xa if k == 3072 else x
-            w = (torch.randn(n * (2 if kw.get("silu") else 1), k, device=dev) * 0.02).half()
-            o = torch.empty(m, n, device=dev).half()
-            r = torch.randn(m, n, device=dev).half() if kw.get("res") else None
-            t1 = timeit(lambda: ops.linear_skinny(a, w, o, ln_w=ln if kw.get("ln") else None, silu=bool(kw.get("silu")), res_out=r))
-            t2 = timeit(lambda: F.linear(a, w))
-            out[f"skinny_m{m}_{name}"] = dict(us=round(t1, 2), hipblaslt_gemm_only_us=round(t2, 2), MB=round(w.numel() * 2 / 1e6, 1))
 for k, v in out.items():
     print(f"{k:34s} {json.dumps(v)}")
