@@ -189,7 +189,10 @@ extern "C" size_t sq_linear_ts_workspace_bytes(int m, int n_out, int splits) {
 
 template <int MT, int NT, bool SILU>
 static void ts_go(const TsParams& P, hipStream_t st) {
-    constexpr int D = (MT * NT > 24) ? 3 : 4;                // vmcnt holds 63 loads: D (NT + MT) must stay below
+    // ring depth: the vmcnt counter tracks 63 loads, so D (NT + MT) must stay below.  Measured on MI355X: deeper
+    // rings (up to 8) and 8-wave workgroups are no faster -- the stream is bound by the CU's vector-memory ingest
+    // (~14 B/clk/CU for weights + activations together), not by bytes in flight.
+    constexpr int D = (MT * NT > 24) ? 3 : 4;
     const size_t lds = (size_t)TS_WAVES * MT * 16 * (NT * 16 + 4) * sizeof(float);
     auto kern = ts_linear_kernel<MT, NT, D, SILU>;
     static bool attr_done = false;
