@@ -125,6 +125,28 @@ def kernel_rooflines(cfg, loop, device):
     t = timeit(comp, 192)
     res["kv_compact_target"] = dict(seconds=t, bytes=4 * 2 * L * Hkv * D * 2 * 2, launches_per_step=1)
     kc.zero_(); vc.zero_()
+    # tall-skinny projections of the verify forward (q = tree size rows), rotating over the layers' weights so
+    # that every launch streams its weights from HBM (32 x 33-180 MB >> the 256 MiB Infinity Cache)
+    ts = getattr(tgt.model, "ts", None)
+    if ts is not None and n <= 128:
+        plan = ts.plan(n)
+        for name in ("qkv", "o", "down"):
+            if plan.get(name) is None:
+                continue
+            tiles, splits = plan[name]
+            n_out, k, _ = ts.shapes[name]
+            xf = ops.repack_rows((torch.randn(n, k, device=device) * 0.5).half())
+            out = torch.empty((n, n_out), dtype=torch.float16, device=device)
+            li = [0]
+
+            def proj(name=name, tiles=tiles, splits=splits, n_out=n_out, k=k, xf=xf, out=out):
+                w = ts.frag(name, li[0] % L)
+                li[0] += 1
+                ops.linear_ts(xf, w, n, n_out, k, out=out, tiles=tiles, splits=splits, slab=ts._slab if splits > 1 else None)
+            t = timeit(proj, 128, 32)
+            out_bytes = splits * n * n_out * 4 if splits > 1 else n * n_out * 2
+            res[f"linear_ts_{name}"] = dict(seconds=t, bytes=n_out * k * 2 + n * k * 2 + out_bytes, launches_per_step=L,
+                                            flops=2 * n * n_out * k, plan=[tiles, splits], pmc_key=f"{name}@{(n + 15) // 16}")
     return res
 
 
@@ -233,7 +255,8 @@ def main():
 
     if rank == 0:
         kr = kernel_rooflines(cfg, loop, device)
-        per_step = {k: v["seconds"] * (v["launches_per_step"] if k == "tree_attention_target" else 1) for k, v in kr.items()}
+        per_step = {k: v["seconds"] * (v["launches_per_step"] if (k == "tree_attention_target" or k.startswith("linear_ts_")) else 1)
+                    for k, v in kr.items()}
         dom = max(per_step, key=per_step.get)
         d = kr[dom]
         peak_hbm = 8000.0
@@ -245,6 +268,13 @@ def main():
                 with open(os.path.join(REPO, "profiles", "r01_pmc_tree_attention.json")) as f:
                     pm = json.load(f)["kernels"]
                 traffic = pm["void tree_attention_kernel<128, true>(AttnParams)|grid=131072"]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        elif dom.startswith("linear_ts_") and args.config == "B":
+            # same recipe over tools/ts_bench at this projection's shape and launch plan, profiles/r01_pmc_ts_linear.json
+            try:
+                with open(os.path.join(REPO, "profiles", "r01_pmc_ts_linear.json")) as f:
+                    traffic = json.load(f)["kernels"][d["pmc_key"]]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         roof = dict(bound="hbm", kernel=dom, achieved=d["bytes"] / d["seconds"] / 1e9, peak=peak_hbm, unit="GB/s",
