@@ -136,23 +136,24 @@ class TsLinearSet:
         if p is None:
             p = {}
             mtp = (q_len + 15) // 16
+            capturing = torch.cuda.is_current_stream_capturing()
             for name in self.NAMES:
                 n_out, k, silu = self.shapes[name]
-                key = plan_key(n_out, k, silu, mtp)
-                rec = shipped_plans().get(key)
-                if rec != "torch" and (name, 0) not in self._frag and not self._images_fit(name):
+                rec = shipped_plans().get(plan_key(n_out, k, silu, mtp))
+                have_images = (name, 0) in self._frag
+                if capturing and (rec is None or not have_images):
+                    rec = "torch"          # no timing, no allocation, no repack inside a capture (the eager warm-ups
+                    #                        of a graph runner come first and cache the real plan)
+                elif rec != "torch" and not have_images and not self._images_fit(name):
                     rec = "torch"
-                if rec is None:
-                    if torch.cuda.is_current_stream_capturing():
-                        rec = "torch"                      # never time inside a capture; the eager warm-ups tune first
-                    else:
-                        rec = self.autotune(name, q_len)
+                elif rec is None:
+                    rec = self.autotune(name, q_len)
                 p[name] = None if rec == "torch" else (int(rec[0]), int(rec[1]))
-            for name, v in p.items():                       # materialise the weight images outside any capture
-                if v is not None:
-                    for li in range(1 if name == "lm_head" else len(self.W.layers)):
-                        self.frag(name, li)
-            if not torch.cuda.is_current_stream_capturing():
+            if not capturing:
+                for name, v in p.items():                   # materialise the weight images now, outside any capture
+                    if v is not None:
+                        for li in range(1 if name == "lm_head" else len(self.W.layers)):
+                            self.frag(name, li)
                 self._plans[q_len] = p
         return p
 

@@ -438,338 +438,6 @@ def test_top_p_filter(ops, V, gain, top_p):
 
 
 @pytest.mark.parametrize("H,Hkv,D,M,gt,n,q_slot0,q_len", [
-    (4, 4, 64, 96, 12, 4, 0, 15),          # prefill + tiny tree, FI-style dims
-    (12, 12, 64, 384, 128, 128, 128, 34),  # draft level of config B
-    (32, 32, 128, 384, 129, 128, 128, 128),  # target verify of config B
-    (8, 2, 128, 256, 40, 65, 0, 104),      # GQA, first verify call (prefix + tree)
-    (8, 1, 128, 1024, 700, 129, 699, 129),  # config E shard: 8 q-heads on 1 KV head, long prefix
-])
-def test_tree_attention_vs_fp32_reference(ops, H, Hkv, D, M, gt, n, q_slot0, q_len):
-    rng = np.random.RandomState(H * 7 + q_len)
-    succ, bm, q, k, v, mask, kv_len = _attn_case(rng, H, Hkv, D, M, gt, n, q_slot0, q_len)
-    scale = 1.0 / np.sqrt(D)
-    want = O.tree_attention(q, k, v, kv_len, scale, mask).astype(np.float32)
-    out = torch.empty(q_len, H * D, dtype=torch.float16, device=DEV)
-    ops.tree_attention(dev(q), dev(k), dev(v), out, kv_len, scale, q_slot0=q_slot0, gt=gt, n_tree=n,
-                       bitmask=dev(bm.view(np.int64)))
-    got = out.cpu().numpy().astype(np.float32)
-    # P is rounded to fp16 before the P·V MFMA (as in the reference's fp16 matmul) and the output
-    # to fp16: tolerance 4e-3 absolute on unit-variance V.
-    assert np.isfinite(got).all()
-    assert np.abs(got - want).max() < 4e-3, np.abs(got - want).max()
-    # dense-mask mode (drop-in signature) gives the same bits as the implicit tree mask
-    out2 = torch.empty_like(out)
-    ops.tree_attention(dev(q), dev(k), dev(v), out2, kv_len, scale, dense_mask=dev(mask))
-    assert torch.equal(out, out2)
-
-
-# ---- a2 -----------------------------------------------------------------------------------------
-def _check_topk(got, want, keys):
-    """identical where the key is unique; inside an exact fp16 tie both must carry the same key"""
-    assert got.shape == want.shape
-    bad = np.argwhere(got != want)
-    for r, c in bad:
-        assert keys[r, got[r, c]] == keys[r, want[r, c]], (r, c)
-    return len(bad)
-
-
-@pytest.mark.parametrize("V,n_rows,k,gain", [(1024, 5, 7, 3.0), (32000, 19, 13, 4.0), (32000, 1, 19, 2.0),
-                                             (32000, 3, 64, 6.0), (4096, 8, 1, 1.0)])
-def test_sample_wor(ops, V, n_rows, k, gain):
-    rng = np.random.RandomState(V + k)
-    R = n_rows + 3
-    logits = (rng.randn(R, V) * gain).astype(np.float16)
-    rand = (rng.randint(0, 2048, size=(R, V)) / 2048.0).astype(np.float16)   # torch's fp16 uniform_ grid
-    rows = rng.permutation(R)[:n_rows].astype(np.int32)
-    want = O.sample_wor(logits[rows], rand[rows], k, 0.6)
-    keys = O.sample_keys(logits[rows], rand[rows], 0.6)
-    out = torch.zeros(n_rows * k, dtype=torch.int64, device=DEV)
-    ops.sample_wor(dev(logits), dev(rand), dev(rows), k, 0.6, out)
-    got = out.cpu().numpy().reshape(n_rows, k)
-    # keys come from exp()/log() whose last-ulp differs between libm and the GPU: a differing pick
-    # must be an exact-or-adjacent fp16 key (1 ulp); otherwise identical.
-    bad = np.argwhere(got != want)
-    for r, c in bad:
-        a = int(keys[r, got[r, c]].view(np.int16)); b = int(keys[r, want[r, c]].view(np.int16))
-        assert abs(a - b) <= 1, (r, c, keys[r, got[r, c]], keys[r, want[r, c]])
-    assert len(bad) <= max(1, got.size // 50)
-    # fused gather mode: tokens[out_off[r] + s] for s < branch[r]
-    branch = rng.randint(0, k + 1, size=n_rows).astype(np.int32)
-    off = (np.concatenate([[0], np.cumsum(branch)[:-1]]) + 11).astype(np.int32)
-    buf = torch.full((11 + int(branch.sum()) + 5,), -7, dtype=torch.int64, device=DEV)
-    ops.sample_wor(dev(logits), dev(rand), dev(rows), k, 0.6, buf, branch=dev(branch), out_off=dev(off))
-    b = buf.cpu().numpy()
-    assert (b[:11] == -7).all() and (b[11 + branch.sum():] == -7).all()
-    assert np.array_equal(b[11:11 + branch.sum()], O.gather_branches(got, branch))
-
-
-@pytest.mark.parametrize("V,n_rows,k", [(1024, 4, 8), (32000, 9, 8), (32000, 56, 1)])
-def test_topk(ops, V, n_rows, k):
-    rng = np.random.RandomState(V + n_rows)
-    logits = (rng.randn(n_rows, V) * 2).astype(np.float16)
-    logits[0, 5] = logits[0, 900] = np.float16(9.0)   # forced exact tie -> lower id first
-    want = O.topk_ids(logits, k)
-    out = torch.zeros(n_rows * k, dtype=torch.int64, device=DEV)
-    ops.topk(dev(logits), None, k, out)
-    assert np.array_equal(out.cpu().numpy().reshape(n_rows, k), want)   # bit-exact incl. tie order
-
-
-def test_sampler_golden_rows(ops):
-    """The reference's own outputs on V = 32000 rows (tests/golden/rows_v32000.npz)."""
-    z = np.load(f"{GOLDEN}/rows_v32000.npz")
-    for i in range(4):
-        logits, rand, k = z[f"wor{i}/logits"], z[f"wor{i}/rand"], int(z[f"wor{i}/k"])
-        out = torch.zeros(2 * k, dtype=torch.int64, device=DEV)
-        ops.sample_wor(dev(logits), dev(rand), None, k, 0.6, out)
-        got = out.cpu().numpy().reshape(2, k)
-        want = z[f"wor{i}/out"].reshape(2, k)
-        keys = O.sample_keys(logits, rand, 0.6)
-        bad = np.argwhere(got != want)
-        for r, c in bad:
-            a = int(keys[r, got[r, c]].view(np.int16)); b = int(keys[r, want[r, c]].view(np.int16))
-            assert abs(a - b) <= 1
-        out = torch.zeros(2 * k, dtype=torch.int64, device=DEV)
-        ops.topk(dev(logits), None, k, out)
-        got = out.cpu().numpy().reshape(2, k)
-        # bit-exact vs the oracle (ties -> lower id); vs torch.topk identical up to the order
-        # inside an exact fp16 tie, which torch leaves unspecified
-        assert np.array_equal(got, O.topk_ids(logits, k))
-        _check_topk(got, z[f"wor{i}/argmax_out"].reshape(2, k), logits)
-
-
-# ---- a6/a7/a8 -----------------------------------------------------------------------------------
-def _run_verify_stochastic(ops, target, draft, tokens, r16, succ, gt, T, u24):
-    n = len(succ)
-    off, ids = csr(succ)
-    d_tokens, d_draft = dev(tokens), dev(draft)
-    ws = ops.verify_workspace(n, DEV)
-    res = torch.zeros(64 + n, dtype=torch.int32, device=DEV)
-    ops.verify_stochastic(dev(target), d_draft, d_tokens, dev(r16), dev(off), dev(ids) if len(ids) else None, n, gt,
-                          T, u24, ws, res)
-    return res.cpu().numpy(), d_tokens.cpu().numpy(), d_draft.cpu().numpy()
-
-
-@pytest.mark.parametrize("name", STOCHASTIC_TRACES)
-def test_verify_stochastic_on_reference_traces(ops, name):
-    """Inputs recorded from the reference run; the kernel must reproduce the reference's accepted
-    tokens, bonus and -65504 writes.  A decision is allowed to differ only when the oracle's
-    accept margin |p[tok] - r*q[tok]| is below 1 fp16 ulp of p (exp() last-ulp effects)."""
-    z, meta = load_trace(name)
-    succ = meta["successors"]
-    n = len(succ)
-    for s in range(int(z["n_steps"])):
-        gt = int(z[f"step{s}/gt"])
-        tokens = z[f"step{s}/tokens_pre"].copy()
-        draft = z[f"step{s}/draft_logits_pre"].copy()
-        target = z[f"step{s}/target_logits"]
-        u24 = int(z["bonus_u24"][s])
-        res, tok_after, draft_after = _run_verify_stochastic(ops, target, draft, tokens, z["r"], succ, gt, meta["T"], u24)
-        margins = []
-        o_tokens, o_draft = tokens.copy(), draft.copy()
-        want = O.verify_stochastic(target, o_draft, o_tokens, z["r"], succ, gt, meta["T"], u24, margins=margins)
-        if res[0] != want["accept_len"]:
-            assert min(abs(m) for m in margins) < 1e-3, (name, s, res[:8], want)
-            continue
-        assert res[1] == want["n_tree"] and res[3] == want["terminal"] and res[4] == want["reason"]
-        assert list(res[8:8 + res[1]]) == want["slots"]
-        a = want["accept_len"]
-        assert np.array_equal(tok_after[:a], o_tokens[:a])
-        assert np.array_equal(tok_after[:a], z[f"step{s}/valid_tokens"][:a])      # == the reference itself
-        # the -65504 writes are identical (integer positions)
-        assert np.array_equal(draft_after == np.float16(-65504), o_draft == np.float16(-65504))
-        if not want["terminal"]:
-            # bonus: exact inverse CDF; residual differs by <= 1 ulp -> allow a neighbouring draw only
-            # when the cdf boundary is within that ulp; in practice identical
-            assert res[2] == want["bonus"], (name, s)
-            assert tok_after[a] == want["bonus"]
-
-
-@pytest.mark.parametrize("V,n,seed", [(1024, 40, 0), (32000, 128, 1), (32000, 6, 2)])
-def test_verify_stochastic_random(ops, V, n, seed):
-    rng = np.random.RandomState(seed)
-    succ = random_tree(rng, n, max_children=8)
-    gt, M = 30, 30 + n + 8
-    T = 0.6
-    agree, total = 0, 0
-    for trial in range(3):
-        target = (rng.randn(n, V) * 3).astype(np.float16)
-        # correlated draft so that both accepts and rejects occur
-        draft = (target.astype(np.float32) + rng.randn(n, V) * 1.5).astype(np.float16)
-        tokens = rng.randint(3, V, size=M).astype(np.int64)
-        # children tokens drawn from the draft distribution (like the real sampler)
-        for p, ch in enumerate(succ):
-            if ch:
-                rand = (rng.randint(0, 2048, size=(1, V)) / 2048.0).astype(np.float16)
-                picks = O.sample_wor(draft[p:p + 1], rand, len(ch), T)[0]
-                for c, tk in zip(ch, picks):
-                    tokens[c + gt - 1] = tk
-        r16 = (rng.randint(0, 2048, size=M) / 2048.0).astype(np.float16)
-        u24 = int(rng.randint(0, 1 << 24))
-        res, tok_after, draft_after = _run_verify_stochastic(ops, target, draft.copy(), tokens.copy(), r16, succ, gt, T, u24)
-        margins = []
-        o_tokens, o_draft = tokens.copy(), draft.copy()
-        want = O.verify_stochastic(target, o_draft, o_tokens, r16, succ, gt, T, u24, margins=margins)
-        total += 1
-        if res[0] == want["accept_len"] and list(res[8:8 + res[1]]) == want["slots"]:
-            agree += 1
-            assert res[3] == want["terminal"]
-            if not want["terminal"] and res[2] != want["bonus"]:
-                # neighbouring token in cdf order is the only legal deviation
-                assert abs(int(res[2]) - int(want["bonus"])) < V
-            a = want["accept_len"]
-            assert np.array_equal(tok_after[:a], o_tokens[:a])
-        else:
-            assert min(abs(m) for m in margins) < 1e-3
-    assert agree >= total - 1
-
-
-def test_verify_stochastic_nan_and_eos(ops):
-    V, gt = 1024, 8
-    succ = [[1, 2], [3], [], []]
-    n = len(succ)
-    rng = np.random.RandomState(5)
-    # p == q exactly and r = 1 -> reject every child, residual 0/0 -> NaN -> terminal (reason 2)
-    target = (rng.randn(n, V) * 2).astype(np.float16)
-    draft = target.copy()
-    tokens = np.arange(3, 3 + gt + n + 2).astype(np.int64)
-    r16 = np.ones(gt + n + 2, dtype=np.float16)
-    res, _, _ = _run_verify_stochastic(ops, target, draft.copy(), tokens.copy(), r16, succ, gt, 0.6, 12345)
-    want = O.verify_stochastic(target, draft.copy(), tokens.copy(), r16, succ, gt, 0.6, 12345)
-    assert want["terminal"] == 1 and want["reason"] == 2
-    assert res[3] == 1 and res[4] == 2 and res[0] == want["accept_len"]
-    # EOS: child token 2 accepted (r = 0 accepts anything with p > 0) -> terminal (reason 1)
-    tokens2 = tokens.copy(); tokens2[1 + gt - 1] = 2
-    r0 = np.zeros_like(r16)
-    res, tok_after, _ = _run_verify_stochastic(ops, target, draft.copy(), tokens2.copy(), r0, succ, gt, 0.6, 7)
-    want = O.verify_stochastic(target, draft.copy(), tokens2.copy(), r0, succ, gt, 0.6, 7)
-    assert want["terminal"] == 1 and want["reason"] == 1
-    assert res[3] == 1 and res[4] == 1 and res[0] == want["accept_len"] and res[2] == -1
-
-
-def test_verify_greedy(ops):
-    z, meta = load_trace("C_greedy8x8")
-    succ = meta["successors"]
-    n = len(succ)
-    off, ids = csr(succ)
-    for s in range(int(z["n_steps"])):
-        gt = int(z[f"step{s}/gt"])
-        tokens = z[f"step{s}/tokens_pre"].copy()
-        d_tokens = dev(tokens)
-        ws = ops.verify_workspace(n, DEV)
-        res = torch.zeros(64 + n, dtype=torch.int32, device=DEV)
-        ops.verify_greedy(dev(z[f"step{s}/target_logits"]), d_tokens, dev(off), dev(ids), n, gt, ws, res)
-        want = O.verify_greedy(z[f"step{s}/target_logits"], tokens, succ, gt)
-        r = res.cpu().numpy()
-        assert r[0] == want["accept_len"] == int(z[f"step{s}/accept_len"])
-        assert r[2] == want["bonus"] and r[3] == want["terminal"]
-        valid = z[f"step{s}/valid_tokens"]
-        assert np.array_equal(d_tokens.cpu().numpy()[:valid.shape[0]], valid)   # bit-exact vs the reference
-
-
-# ---- row-wise glue --------------------------------------------------------------------------------
-def test_rmsnorm_silu(ops):
-    rng = np.random.RandomState(3)
-    rows, hidden, inter = 37, 768, 3072
-    x = torch.from_numpy(rng.randn(rows, hidden).astype(np.float16)).to(DEV)
-    res = torch.from_numpy(rng.randn(rows, hidden).astype(np.float16)).to(DEV)
-    w = torch.from_numpy((1 + 0.1 * rng.randn(hidden)).astype(np.float16)).to(DEV)
-
-    def ref_norm(h):   # Engine/Llama_modules.py:282-288 expressed with torch ops on the GPU
-        hf = h.float()
-        var = hf.pow(2).mean(-1, keepdim=True)
-        return w * (hf * torch.rsqrt(var + 1e-6)).half()
-    out = torch.empty_like(x)
-    ops.rmsnorm(x, w, out, 1e-6)
-    assert (out.float() - ref_norm(x).float()).abs().max() < 2e-3
-    s = torch.empty_like(x)
-    ops.add_rmsnorm(x, res, s, w, out, 1e-6)
-    assert torch.equal(s, x + res)
-    assert (out.float() - ref_norm(x + res).float()).abs().max() < 2e-3
-    gu = torch.from_numpy(rng.randn(rows, 2 * inter).astype(np.float16)).to(DEV)
-    o = torch.empty(rows, inter, dtype=torch.float16, device=DEV)
-    ops.silu_mul(gu, o)
-    want = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
-    assert (o.float() - want.float()).abs().max() < 4e-3
-
-
-def test_verify_greedy_deep_chain(ops):
-    """Accepted path longer than the 56-slot header: the full list follows the header."""
-    n, V, gt = 100, 1024, 10
-    succ = [[i + 1] for i in range(n - 1)] + [[]]
-    off, ids = csr(succ)
-    rng = np.random.RandomState(9)
-    tokens = rng.randint(3, V, size=gt + n + 4).astype(np.int64)
-    logits = (rng.randn(n, V)).astype(np.float16)
-    for t in range(n - 1):           # node t's target argmax == the token of its only child
-        logits[t, tokens[t + 1 + gt - 1]] = np.float16(30.0)
-    d_tokens = dev(tokens)
-    ws = ops.verify_workspace(n, DEV)
-    res = torch.zeros(64 + n, dtype=torch.int32, device=DEV)
-    ops.verify_greedy(dev(logits), d_tokens, dev(off), dev(ids), n, gt, ws, res)
-    o_tokens = tokens.copy()
-    want = O.verify_greedy(logits, o_tokens, succ, gt)
-    r = res.cpu().numpy()
-    assert want["n_tree"] == n - 1 and r[1] == n - 1 and r[0] == want["accept_len"]
-    assert list(r[64:64 + n - 1]) == want["slots"] and list(r[8:64]) == want["slots"][:56]
-    assert np.array_equal(d_tokens.cpu().numpy()[:want["accept_len"] + 1], o_tokens[:want["accept_len"] + 1])
-
-
-@pytest.mark.parametrize("V,gain,top_p", [(32000, 3.0, 0.9), (32000, 1.0, 0.5), (32000, 8.0, 0.9), (1024, 2.0, 0.3)])
-def test_top_p_filter(ops, V, gain, top_p):
-    rng = np.random.RandomState(int(V * top_p))
-    logits = (rng.randn(6, V) * gain).astype(np.float16)
-    logits[1, :64] = np.float16(2.5)            # a big exact tie group
-    want = O.top_p_filter(logits, top_p, 0.6)
-    d = dev(logits)
-    ops.top_p_filter(d, top_p, 0.6)
-    got = d.cpu().numpy()
-    # exp() last-ulp differences can move the cut by a token; otherwise bit-identical
-    diff = (np.isinf(got) != np.isinf(want)).sum(axis=1)
-    assert diff.max() <= 2, diff
-    same = np.isinf(got) == np.isinf(want)
-    assert np.array_equal(got[same], want[same])
-    # reference outputs on the golden rows
-    if V == 32000 and top_p == 0.9:
-        z = np.load(f"{GOLDEN}/rows_v32000.npz")
-        for i in range(4):
-            d = dev(z[f"wor{i}/logits"])
-            ops.top_p_filter(d, 0.9, 0.6)
-            assert (np.isinf(d.cpu().numpy()) != np.isinf(z[f"wor{i}/topp09"])).sum(axis=1).max() <= 6
-
-
-@pytest.mark.parametrize("m,n,k", [(1, 2304, 768), (34, 768, 768), (19, 3072, 768), (31, 768, 3072), (64, 32000, 768),
-                                    (16, 96, 128)])
-def test_linear_skinny(ops, m, n, k):
-    """Fused skinny projections vs the unfused expression on the GPU (same fp16 rounding points; only the
-    fp32 accumulation order differs from hipBLASLt): plain, RMSNorm prologue, SiLU*up epilogue, residual."""
-    g = torch.Generator(device=DEV).manual_seed(m * 7 + n)
-    a = (torch.randn(m, k, generator=g, device=DEV)).half()
-    w = (torch.randn(n, k, generator=g, device=DEV) * 0.05).half()
-    ln = (1 + 0.1 * torch.randn(k, generator=g, device=DEV)).half()
-    res = torch.randn(m, n, generator=g, device=DEV).half()
-
-    def norm(x):
-        xf = x.float()
-        return ln * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).half()
-    tol = dict(atol=2e-2, rtol=2e-2)
-    out = torch.empty(m, n, dtype=torch.float16, device=DEV)
-    ops.linear_skinny(a, w, out)
-    assert torch.allclose(out.float(), (a.float() @ w.float().t()), **tol)
-    ops.linear_skinny(a, w, out, ln_w=ln, eps=1e-6)
-    assert torch.allclose(out.float(), norm(a).float() @ w.float().t(), **tol)
-    out2 = res.clone()
-    ops.linear_skinny(a, w, out2, res_out=out2)                   # in-place residual
-    assert torch.allclose(out2.float(), ((a.float() @ w.float().t()).half() + res).float(), **tol)
-    if n % 2 == 0:
-        h = n // 2
-        o3 = torch.empty(m, h, dtype=torch.float16, device=DEV)
-        ops.linear_skinny(a, w, o3, ln_w=ln, eps=1e-6, silu=True)
-        y = (norm(a).float() @ w.float().t()).half()
-        want = (torch.nn.functional.silu(y[:, :h]) * y[:, h:]).float()
-        assert torch.allclose(o3.float(), want, **tol)
-
-
-@pytest.mark.parametrize("H,Hkv,D,M,gt,n,q_slot0,q_len", [
     (12, 12, 64, 384, 128, 128, 147, 34),    # draft level
     (32, 32, 128, 384, 129, 128, 128, 128),  # 7B verify
     (8, 2, 128, 256, 40, 65, 0, 104),        # GQA, prefill + tree in one call (all rows new)

@@ -206,3 +206,36 @@ def test_ts_forward_matches_general_forward():
     d = (out_ts.float() - out_ref.float()).abs().max().item()
     assert d <= 4e-2, d
     assert torch.equal(out_ts.argmax(-1), out_ref.argmax(-1))
+
+
+def test_autotune_returns_a_usable_plan_and_never_runs_inside_a_capture():
+    from sequoia_amd.Engine import ts_linear
+    from sequoia_amd.Engine.Llama_model import LlamaDims, LlamaWeights
+    cfg = dict(vocab_size=2048, hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+               num_key_value_heads=2, max_position_embeddings=2048)
+    W = LlamaWeights.random(LlamaDims.from_any(cfg), torch.float16, DEV, 1)
+    ts = ts_linear.TsLinearSet(W, W.dims)
+    for name in ts.NAMES:
+        rec = ts.autotune(name, 20)
+        n_out, k, silu = ts.shapes[name]
+        assert rec == "torch" or (rec in [list(c) for c in ts_linear.candidates(n_out, k, silu, 20, name in ts_linear.SPLITTABLE)])
+        key = ts_linear.plan_key(n_out, k, silu, 2)
+        assert ts.tuned[key]["torch_us"] > 0 and ts.tuned[key]["ts_us"]
+    # a plan requested for the first time during capture falls back to torch for unknown shapes and is not cached
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            p = ts.plan(33)
+    assert all(v is None for v in p.values()) and 33 not in ts._plans
+
+
+def test_plan_candidates_respect_kernel_limits():
+    from sequoia_amd.Engine.ts_linear import candidates
+    for n_out, k, silu, m in [(12288, 4096, False, 128), (11008, 4096, True, 48), (11008, 4096, True, 128), (768, 3072, False, 34),
+                              (32000, 768, False, 1)]:
+        units = n_out // 16
+        for tiles, splits in candidates(n_out, k, silu, m, allow_split=not silu):
+            per = (units + tiles - 1) // tiles
+            assert per <= ((3 if m <= 64 else 2) if silu else 4)
+            assert k // 32 >= splits * 8 and (splits == 1 or not silu)
