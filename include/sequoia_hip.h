@@ -207,6 +207,31 @@ int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens,
                          int n_tree, int vocab, int gt, void* workspace, int32_t* d_result,
                          void* stream);
 
+/* ---- the comparison baselines of the paper on the same kernels ------------ */
+/* SpecInferTree.collective_grow_static (Tree/SpecInferTree.py:104-109): k draws WITH replacement per
+ * row from softmax(logits / T).  Draw j of row i is the exact inverse CDF (token order, integer
+ * arithmetic on the 2^-24 grid) at d_u24[i*k + j] / 2^24 -- explicit uniforms replace torch's device
+ * multinomial stream.  Rows / output placement as in sq_sample_wor_f16.                          */
+int sq_sample_iid_f16(const void* logits, int64_t ld, const int32_t* d_row_ids, int n_rows, int vocab,
+                      int k, float temperature, const uint32_t* d_u24, int64_t* d_out,
+                      const int32_t* d_branch, const int32_t* d_out_off, void* stream);
+
+/* SpecInferTree.verify / accept_step (Tree/SpecInferTree.py:141-164,167-247): as
+ * sq_verify_stochastic_f16, except that a child is accepted iff p[tok] >= r q[tok] and a rejection
+ * only replaces p by the residual -- q keeps the rejected token (the children were drawn with
+ * replacement) and the draft logits are not modified.                                           */
+int sq_verify_specinfer_f16(const void* target_logits, const void* draft_logits, int64_t* tokens,
+                            const void* r, const int32_t* d_child_off, const int32_t* d_child_ids,
+                            int n_tree, int vocab, int gt, float temperature, uint32_t bonus_u24,
+                            void* workspace, int32_t* d_result, void* stream);
+
+/* GreedySTree.verify (Tree/GreedySTree.py:188-214): the walk of sq_verify_greedy_f16 against one
+ * target token per node supplied by the caller (sampled from the target distribution instead of
+ * the argmax); bonus = the target token of the last accepted node.  d_target_tokens: int64 [n_tree]. */
+int sq_verify_tokens_f16(const int64_t* d_target_tokens, int64_t* tokens, const int32_t* d_child_off,
+                         const int32_t* d_child_ids, int n_tree, int gt, void* workspace,
+                         int32_t* d_result, void* stream);
+
 /* ---- row-wise glue of the Llama block (launch removal on the draft side) --- */
 /* LlamaRMSNorm_FI.forward (Engine/Llama_modules.py:274-288): fp32 variance, normalised value
  * cast to fp16, then fp16 multiply by the weight.  x, out: fp16 [rows][hidden].              */

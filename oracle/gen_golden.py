@@ -50,6 +50,8 @@ def import_reference():
     from Engine.Llama_KV import KV_Cache
     from Tree.SpecTree import SpecTree
     from Tree.GreedyTree import GreedyTree
+    from Tree.SpecInferTree import SpecInferTree
+    from Tree.GreedySTree import GreedySTree
     import utils as RU
     from transformers import LlamaConfig
 
@@ -59,7 +61,8 @@ def import_reference():
             return 10000.0
 
     return dict(LM=LM, MM=MM, GIE=GraphInferenceEngine, GIETG=GraphInferenceEngineTG, IE=InferenceEngine,
-                IETG=InferenceEngineTG, KV=KV_Cache, SpecTree=SpecTree, GreedyTree=GreedyTree, RU=RU,
+                IETG=InferenceEngineTG, KV=KV_Cache, SpecTree=SpecTree, GreedyTree=GreedyTree, SpecInferTree=SpecInferTree,
+                GreedySTree=GreedySTree, RU=RU,
                 Cfg=Cfg436)
 
 
@@ -101,7 +104,8 @@ def kv_checksum(engine):
 
 def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, prompt_len, max_steps, seed,
              logit_gain=24.0, share_weights=0.0, out_dir=None):
-    """mode: 'stochastic' (SpecTree) or 'greedy' (GreedyTree)."""
+    """mode: 'stochastic' (SpecTree), 'greedy' (GreedyTree), 'specinfer' (SpecInferTree: draws with replacement)
+    or 'greedys' (GreedySTree: greedy draft tree, target token sampled per node)."""
     RU = R["RU"]
     g = torch.load(growmap_path, weights_only=False)
     n = g["size"]
@@ -130,7 +134,15 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
     arrays["bonus_u24"] = u24
 
     n_levels = len(g["roots"]) - 1
-    if mode == "stochastic":
+    kmax = max([max(b) for b in g["branches"][:n_levels]] + [1])
+    rs = np.random.RandomState(seed + 2)
+    draw_u24 = rs.randint(0, 1 << 24, size=(max_steps + 1, n, kmax)).astype(np.int64)      # specinfer: draft draws
+    target_u24 = rs.randint(0, 1 << 24, size=(max_steps + 1, n)).astype(np.int64)          # greedys: target tokens
+    if mode == "specinfer":
+        arrays["draw_u24"] = draw_u24
+    if mode == "greedys":
+        arrays["target_u24"] = target_u24
+    if mode in ("stochastic", "specinfer"):
         samp = {i: (lambda k: lambda lg, rnd: RU.sampling_without_replacement(lg, rnd, k, T))(max(g["branches"][i]))
                 for i in range(n_levels)}  # shim 5
     else:
@@ -155,13 +167,27 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
 
     def fake_multinomial(self, num_samples=1, replacement=False, generator=None):
         p = self.detach().clone().numpy()
+        if p.ndim == 2 and mode == "specinfer":
+            # draft draws with replacement (Tree/SpecInferTree.py:108): row i belongs to node rows[i]
+            rows = step_box["rows"]
+            out = np.zeros((p.shape[0], num_samples), dtype=np.int64)
+            for i in range(p.shape[0]):
+                for j in range(num_samples):
+                    out[i, j] = ops_np.inverse_cdf(p[i], int(draw_u24[step_box["i"], rows[i], j]))
+            return torch.from_numpy(out)
+        if p.ndim == 2 and mode == "greedys":
+            # one target token per node (Tree/GreedySTree.py:190)
+            out = np.array([[ops_np.inverse_cdf(p[i], int(target_u24[step_box["i"], i]))] for i in range(p.shape[0])])
+            step_box["target_token"] = out[:, 0].copy()
+            return torch.from_numpy(out.astype(np.int64))
         step_box["last_residual"] = p
         tok = ops_np.inverse_cdf(p, int(u24[step_box["i"]]))
         return torch.tensor([tok], dtype=torch.long)
 
     torch.Tensor.multinomial = fake_multinomial
     try:
-        cls = R["SpecTree"] if mode == "stochastic" else R["GreedyTree"]
+        cls = {"stochastic": R["SpecTree"], "greedy": R["GreedyTree"], "specinfer": R["SpecInferTree"],
+               "greedys": R["GreedySTree"]}[mode]
         torch.manual_seed(seed + 7)  # noise seed: r then rand are drawn inside the ctor
         tree = cls(prefix=prefix, device="cpu", temperature=T, top_p=1.0, draft_kv_len=0, target_kv_len=0,
                    draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
@@ -170,9 +196,16 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
                    position_ids=torch.zeros(M).long(),
                    residual_graph=RU.get_residual, sampling_callables=samp, sample_gather_indices=gidx,
                    vocab_size=vocab)
-        if mode == "stochastic":
+        if mode in ("stochastic", "specinfer"):
             arrays["r"] = tree.r.numpy().copy()
             arrays["rand"] = tree.rand.numpy().copy()
+        if mode == "specinfer":
+            grow = tree.collective_grow_static
+
+            def grow_spy(idx_list, n_branch_list, benchmark=False, grow_step=None):
+                step_box["rows"] = list(idx_list)
+                return grow(idx_list, n_branch_list, benchmark=benchmark, grow_step=grow_step)
+            tree.collective_grow_static = grow_spy
         arrays["draft_logits0_prefill"] = tree.draft_logits[0].numpy().copy()
         # mask semantics probe for the first window
         arrays["mask_window0"] = tree.attn_mask[:prefix.shape[0] + n - 1, :prefix.shape[0] + n - 1].numpy().copy()
@@ -183,6 +216,7 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
         while step < max_steps and not terminal and cur_len + n < M:
             gt = tree.ground_truth_len
             samp_log.clear()
+            step_box["i"] = step
             tree.construct_grow_map()
             pre = f"step{step}"
             arrays[f"{pre}/gt"] = np.int64(gt)
@@ -214,6 +248,8 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
             arrays[f"{pre}/tokens_post"] = tree.tokens.numpy().copy()
             if step_box["last_residual"] is not None:
                 arrays[f"{pre}/residual"] = step_box["last_residual"]
+            if mode == "greedys":
+                arrays[f"{pre}/target_token"] = step_box["target_token"]
             arrays[f"{pre}/draft_logits_post"] = tree.draft_logits[:n].numpy().copy()
             arrays[f"{pre}/kv_draft"] = kv_checksum(draft)
             arrays[f"{pre}/kv_target"] = kv_checksum(target)
@@ -288,6 +324,11 @@ def main():
     # config E shape (64x2) stochastic with GQA target
     run_case(R, "E_64x2", gm("L40_growmaps/64x2-tree.pt"), tiny, gqa_t, 1024, 224, 0.6, "stochastic", 16, 2, 21,
              logit_gain=6.0, out_dir=out_dir)
+    # the paper's comparison baselines on the same harness
+    run_case(R, "F_specinfer", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "specinfer", 20, 4, 22,
+             logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
+    run_case(R, "G_greedys", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "greedys", 20, 4, 23,
+             logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
     gen_rows_fullvocab(R, out_dir)
 
 

@@ -117,6 +117,25 @@ class OracleOps:
         self._fill(result, res)
         return result
 
+    def sample_iid(self, logits, u24, row_ids, k, temperature, out, branch=None, out_off=None):
+        rows = _np(row_ids).astype(np.int64) if row_ids is not None else np.arange(logits.shape[0])
+        u = _np(u24).reshape(-1)[:len(rows) * k].reshape(len(rows), k) & 0xffffff
+        self._emit(O.sample_iid(_np(logits)[rows], u, k, temperature), out, branch, out_off)
+        return out
+
+    def verify_specinfer(self, target_logits, draft_logits, tokens, r, child_off, child_ids, n_tree, gt, temperature,
+                         u24, workspace, result):
+        succ = _succ_from_csr(child_off, child_ids, n_tree)
+        res = O.verify_specinfer(_np(target_logits), _np(draft_logits), _np(tokens), _np(r), succ, gt, temperature,
+                                 int(u24))
+        self._fill(result, res)
+        return result
+
+    def verify_tokens(self, target_tokens, tokens, child_off, child_ids, n_tree, gt, workspace, result):
+        succ = _succ_from_csr(child_off, child_ids, n_tree)
+        self._fill(result, O.verify_tokens(_np(target_tokens), _np(tokens), succ, gt))
+        return result
+
     def top_p_filter(self, logits, top_p, temperature):
         if top_p < 1.0:
             logits.copy_(torch.from_numpy(O.top_p_filter(_np(logits), top_p, temperature)))

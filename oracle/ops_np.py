@@ -273,8 +273,9 @@ def inverse_cdf(p16, u24):
     return int(np.searchsorted(c, thr, side="right"))
 
 
-def accept_children(p16, draft_row16, child_tokens, child_r16, temperature, margins=None):
-    """accept_step (Tree/SpecTree.py:136-157) for one parent.
+def accept_children(p16, draft_row16, child_tokens, child_r16, temperature, margins=None, replace=False):
+    """accept_step (Tree/SpecTree.py:136-157) for one parent; replace=True is SpecInfer's rule
+    (Tree/SpecInferTree.py:141-164): p >= r q, and a rejection leaves q and the draft logits untouched.
 
     p16: target distribution at the parent (fp16[V]); draft_row16: the parent's draft logits
     (fp16[V], mutated in place like the reference: rejected tokens get -65504);
@@ -286,16 +287,17 @@ def accept_children(p16, draft_row16, child_tokens, child_r16, temperature, marg
         rq = h(f(np.float16(r)) * f(q16[tok]))
         if margins is not None:
             margins.append(float(f(p16[tok]) - f(rq)))
-        if p16[tok] > rq:
+        if (p16[tok] >= rq) if replace else (p16[tok] > rq):
             return j, p16, n_rej
         p16, _ = residual_f16(p16, q16)
-        draft_row16[tok] = F16_MIN
+        if not replace:
+            draft_row16[tok] = F16_MIN
         n_rej += 1
     return -1, p16, n_rej
 
 
 def verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, gt, temperature,
-                      u24, margins=None):
+                      u24, margins=None, replace=False):
     """SpecTree.verify from the softmax to the token compaction (Tree/SpecTree.py:196-224).
 
     target_logits16: [n, V]; draft_logits16: [>=n, V] tree-local rows (mutated); tokens: int64[M]
@@ -312,7 +314,7 @@ def verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, 
             break
         ctoks = [int(tokens[c + gt - 1]) for c in ch]
         crs = [r16[c + gt - 1] for c in ch]
-        j, p, _ = accept_children(p_all[node], draft_logits16[node], ctoks, crs, temperature, margins)
+        j, p, _ = accept_children(p_all[node], draft_logits16[node], ctoks, crs, temperature, margins, replace)
         if j < 0:
             break
         node = ch[j]
@@ -329,10 +331,12 @@ def verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, 
             bonus = inverse_cdf(p, u24)
             if bonus < 0:
                 terminal, reason = True, 2
-    if slots:
-        tokens[gt:a] = tokens[np.asarray(slots)].copy()
+    # the reference stores the bonus token BEFORE the gather (Tree/SpecTree.py:222-224): an accepted node sitting at
+    # slot a is therefore committed with the bonus token's id (quirk reproduced for token parity)
     if not terminal:
         tokens[a] = bonus
+    if slots:
+        tokens[gt:a] = tokens[np.asarray(slots)].copy()
     return dict(accept_len=a, n_tree=len(slots), bonus=bonus, terminal=int(terminal), reason=reason,
                 gt=gt, last_node=node, slots=slots, final_p=p)
 
@@ -460,3 +464,49 @@ def add_rmsnorm_slabs(slabs32, res16, weight16, eps):
     var = (xf * xf).mean(-1, keepdims=True, dtype=np.float32)
     nrm = h(xf * (np.float32(1.0) / np.sqrt(var + np.float32(eps))))
     return total, h(f(weight16) * f(nrm))
+
+
+# ---- the paper's comparison baselines ---------------------------------------------------
+def sample_iid(logits16, u24, k, temperature):
+    """SpecInferTree.collective_grow_static (Tree/SpecInferTree.py:104-109): k draws with replacement per row from
+    softmax(logits / T); draw j of row i = exact inverse CDF at u24[i][j] / 2^24 (explicit uniforms in place of
+    torch's device multinomial stream).  Returns int64 [n, k]."""
+    q = scaled_softmax_f16(logits16, temperature)
+    out = np.zeros((q.shape[0], k), dtype=np.int64)
+    for i in range(q.shape[0]):
+        for j in range(k):
+            out[i, j] = inverse_cdf(q[i], int(u24[i][j]))
+    return out
+
+
+def verify_specinfer(target_logits16, draft_logits16, tokens, r16, successors, gt, temperature, u24, margins=None):
+    """SpecInferTree.verify (Tree/SpecInferTree.py:167-247): SpecTree's walk with the with-replacement accept rule."""
+    return verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, gt, temperature, u24, margins,
+                             replace=True)
+
+
+def verify_tokens(target_tokens, tokens, successors, gt):
+    """GreedySTree.verify after the per-node target draw (Tree/GreedySTree.py:196-214): walk by token equality against
+    target_tokens[node]; bonus = target token of the last accepted node."""
+    node, slots, terminal, reason = 0, [], False, 0
+    while True:
+        nxt = -1
+        for c in successors[node]:
+            if int(tokens[c + gt - 1]) == int(target_tokens[node]):
+                nxt = c
+                break
+        if nxt < 0:
+            break
+        node = nxt
+        slots.append(node + gt - 1)
+        if int(tokens[node + gt - 1]) in EOS_IDS:
+            terminal, reason = True, 1
+            break
+    a = gt + len(slots)
+    bonus = -1 if terminal else int(target_tokens[node])
+    if slots:
+        tokens[gt:a] = tokens[np.asarray(slots)].copy()
+    if not terminal:
+        tokens[a] = bonus
+    return dict(accept_len=a, n_tree=len(slots), bonus=bonus, terminal=int(terminal), reason=reason, gt=gt,
+                last_node=node, slots=slots)

@@ -82,7 +82,7 @@ class NativeTree(Tree):
         self.draft_kv_len = self.num_nodes
         self.target_kv_len = target_kv_len
         if self.stochastic:
-            self.rand = torch.empty((n, vocab_size), dtype=self.dtype).uniform_().to(self.device)
+            self._init_draft_noise(n, vocab_size)
             if bonus_uniforms is None:
                 bonus_uniforms = torch.randint(0, 1 << 24, (self.max_length + 1,))
             self.bonus_u24 = [int(x) for x in bonus_uniforms]
@@ -94,6 +94,11 @@ class NativeTree(Tree):
         self.target_logits = None
 
     # ---- helpers --------------------------------------------------------------------------------
+    def _init_draft_noise(self, n: int, vocab_size: int):
+        """Per-prompt noise of the draft expansion: the [n, V] uniforms of sampling without replacement
+        (Tree/SpecTree.py:84), drawn on the CPU generator right after `r` like the reference."""
+        self.rand = torch.empty((n, vocab_size), dtype=self.dtype).uniform_().to(self.device)
+
     def _ctx(self, q_slot0: int, kv_len: int) -> TreeContext:
         # storage_ids = arange(M) (Tree/SpecTree.py:63): the queries' KV slots are q_slot0 + arange(q_len)
         return TreeContext(q_slot0=q_slot0, gt=self.ground_truth_len, n_tree=self.tree_size,

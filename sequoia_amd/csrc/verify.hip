@@ -78,6 +78,87 @@ __device__ __forceinline__ void row_softmax_f16(const half_t* __restrict__ x, in
     for (int i = 0; i < EPT; ++i) p[i] = (half_t)div_rn(exp_fast((float)p[i] - mx), z);
 }
 
+// Exact inverse CDF of a (possibly unnormalised) fp16 distribution held EPT elements per thread: the token whose
+// cumulative mass interval, in element-index order (chunk, thread, j) and in exact integer arithmetic on the 2^-24
+// grid, contains u24 / 2^24 of the total.  Returns -1 for an all-zero distribution.  Block-uniform result.
+template <int EPT>
+__device__ __forceinline__ int block_inverse_cdf(const half_t (&p)[EPT], int vocab, int t, uint32_t u24) {
+    constexpr int CH = EPT / 8;
+    __shared__ unsigned long long s_ct[VER_WAVES][EPT / 8];
+    __shared__ unsigned long long s_scan[VER_WAVES];
+    __shared__ int s_pick;
+    uint32_t csum[CH];                   // per-thread sum of one 8-element chunk: <= 8 * 2^24
+    unsigned long long total = 0ull, base = 0ull;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        uint32_t sv = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (v_elem(c, t, j) < vocab) sv += (uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+        csum[c] = sv;
+        const unsigned long long wsum = wave_sum_u32_wide_dpp(sv);
+        if ((t & 63) == 0) s_ct[t >> 6][c] = wsum;
+    }
+    __syncthreads();
+    unsigned long long ctot[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        unsigned long long acc = 0ull;
+#pragma unroll
+        for (int w2 = 0; w2 < VER_WAVES; ++w2) acc += s_ct[w2][c];
+        ctot[c] = acc;
+        total += acc;
+    }
+    if (total == 0ull) { __syncthreads(); return -1; }
+    const unsigned long long thr = (__umul64hi((unsigned long long)u24, total) << 40) |
+                                   (((unsigned long long)u24 * total) >> 24);
+    int cstar = CH - 1;
+    unsigned long long run = 0ull;
+    bool found = false;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if (!found && run + ctot[c] > thr) { cstar = c; base = run; found = true; }
+        run += ctot[c];
+    }
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) if (c == cstar) mine = (unsigned long long)csum[c];
+    // inclusive scan of `mine` over the block's threads
+    unsigned long long inc = mine;
+    const int lane = t & 63, w = t >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, o, 64);
+        uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), o, 64);
+        if (lane >= o) inc += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 63) s_scan[w] = inc;
+    if (t == 0) s_pick = -1;
+    __syncthreads();
+    unsigned long long woff = 0ull;
+    for (int i = 0; i < w; ++i) woff += s_scan[i];
+    const unsigned long long excl = base + woff + inc - mine;
+    if (mine > 0ull && excl <= thr && thr < excl + mine) {
+        unsigned long long acc = excl;
+        int pick = -1;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (c == cstar) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc += (unsigned long long)(uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+                    if (pick < 0 && acc > thr) pick = v_elem(c, t, j);
+                }
+            }
+        }
+        s_pick = pick;
+    }
+    __syncthreads();
+    const int res = s_pick;
+    __syncthreads();                       // s_pick / s_ct are reused by the next call
+    return res;
+}
+
 // one block-wide reduction of three quantities at once: exact integer sum, float max, float sum
 struct Red3 { unsigned long long isum; float fmax; float fsum; };
 __device__ __forceinline__ Red3 block_red3(uint32_t isum32, float fmx, float fsum, unsigned long long* s_u,
@@ -98,7 +179,9 @@ __device__ __forceinline__ Red3 block_red3(uint32_t isum32, float fmx, float fsu
     return r;
 }
 
-template <int EPT>
+// REPLACE = SpecInfer's rule (Tree/SpecInferTree.py:141-164): children were drawn WITH replacement, so a rejected
+// token stays in q (no masking, no renormalisation of q) and the test is p >= r q.
+template <int EPT, bool REPLACE>
 __global__ void __launch_bounds__(VER_THREADS)
 verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __restrict__ draft_logits,
                     const int64_t* __restrict__ tokens, const half_t* __restrict__ r16,
@@ -110,8 +193,6 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
     __shared__ float s_s[VER_WAVES];
     __shared__ unsigned long long s_u[VER_WAVES];
     __shared__ float s_tok[2];            // e[tok], p[tok] of the child under test
-    __shared__ unsigned long long s_scan[VER_WAVES];
-    __shared__ int s_bonus;
     const int t = threadIdx.x;
     const int node = blockIdx.x;
     const VerifyWs ws = ws_layout(ws_raw, n_tree);
@@ -163,7 +244,7 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             const half_t q_tok = (half_t)div_rn(s_tok[0], z);
             const half_t p_tok = (half_t)s_tok[1];
             const half_t rq = (half_t)((float)rr * (float)q_tok);
-            const bool ok = (tok >= 0 && tok < vocab) && (p_tok > rq);   // strict, Tree/SpecTree.py:152
+            const bool ok = (tok >= 0 && tok < vocab) && (REPLACE ? (p_tok >= rq) : (p_tok > rq));   // Tree/SpecTree.py:152 (strict)
             if (ok) { accepted = child; break; }
             // reject: p <- relu(p - q) / sum(relu(p - q));  draft_logits[tok] <- -65504 (=> q[tok] = 0)
             uint32_t lint = 0u;
@@ -176,7 +257,7 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
                 di = di > (half_t)0.0f ? di : (half_t)0.0f;      // relu_; NaN p stays out (compares false)
                 p[i] = di;                                       // p now holds the unnormalised residual
                 lint += (uint32_t)((float)di * 16777216.0f);
-                if (mine && i == tok_local) {
+                if (!REPLACE && mine && i == tok_local) {
                     yd[i] = (half_t)(-INFINITY);
                 } else {
                     nmax = fmaxf(nmax, (float)yd[i]);
@@ -191,6 +272,7 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             for (int i = 0; i < EPT; ++i) p[i] = nan_flag ? (half_t)NAN : (half_t)div_rn((float)p[i], sf);
             nrej = jc + 1;
             if (nan_flag) break;          // every later comparison with NaN is false: all rejected
+            if (REPLACE) continue;        // q is unchanged
             if (red.fmax != mx) {         // the removed token was the maximum: rebase the exponentials
                 mx = red.fmax;
                 lsum = 0.f;
@@ -206,77 +288,7 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
 
     int bonus = -1;
     if (accepted < 0 && !nan_flag) {
-        // exact inverse CDF on the 2^-24 grid, element-index order = (chunk, thread, j)
-        uint32_t csum[CH];                   // per-thread sum of one 8-element chunk: <= 8 * 2^24
-        unsigned long long total = 0ull, base = 0ull;
-        __shared__ unsigned long long s_ct[VER_WAVES][EPT / 8];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            uint32_t sv = 0u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (v_elem(c, t, j) < vocab) sv += (uint32_t)((float)p[c * 8 + j] * 16777216.0f);
-            csum[c] = sv;
-            const unsigned long long wsum = wave_sum_u32_wide_dpp(sv);
-            if ((t & 63) == 0) s_ct[t >> 6][c] = wsum;
-        }
-        __syncthreads();
-        unsigned long long ctot[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            unsigned long long acc = 0ull;
-#pragma unroll
-            for (int w2 = 0; w2 < VER_WAVES; ++w2) acc += s_ct[w2][c];
-            ctot[c] = acc;
-            total += acc;
-        }
-        if (total > 0ull) {
-            const unsigned long long thr = (__umul64hi((unsigned long long)u24, total) << 40) |
-                                           (((unsigned long long)u24 * total) >> 24);
-            int cstar = CH - 1;
-            unsigned long long run = 0ull;
-            bool found = false;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                if (!found && run + ctot[c] > thr) { cstar = c; base = run; found = true; }
-                run += ctot[c];
-            }
-            unsigned long long mine = 0ull;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) if (c == cstar) mine = (unsigned long long)csum[c];
-            // inclusive scan of `mine` over the block's threads
-            unsigned long long inc = mine;
-            const int lane = t & 63, w = t >> 6;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, o, 64);
-                uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), o, 64);
-                if (lane >= o) inc += ((unsigned long long)hi << 32) | lo;
-            }
-            if (lane == 63) s_scan[w] = inc;
-            if (t == 0) s_bonus = -1;
-            __syncthreads();
-            unsigned long long woff = 0ull;
-            for (int i = 0; i < w; ++i) woff += s_scan[i];
-            const unsigned long long excl = base + woff + inc - mine;
-            if (mine > 0ull && excl <= thr && thr < excl + mine) {
-                unsigned long long acc = excl;
-                int pick = -1;
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    if (c == cstar) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            acc += (unsigned long long)(uint32_t)((float)p[c * 8 + j] * 16777216.0f);
-                            if (pick < 0 && acc > thr) pick = v_elem(c, t, j);
-                        }
-                    }
-                }
-                s_bonus = pick;
-            }
-            __syncthreads();
-            bonus = s_bonus;
-        }
+        bonus = block_inverse_cdf<EPT>(p, vocab, t, u24);
         if (bonus < 0) nan_flag = 1;      // empty distribution: treated like the NaN residual
     }
     if (t == 0) {
@@ -290,15 +302,19 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
 // One wave.  Walk root -> accepted children; side effects of Tree/SpecTree.py:156,222,224.
 __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const int32_t* __restrict__ child_off,
                                    const int32_t* __restrict__ child_ids, int n_tree, int vocab, int gt,
-                                   void* ws_raw, int32_t* result, int greedy) {
+                                   void* ws_raw, int32_t* result, int mode, const int64_t* __restrict__ tgt_tokens) {
+    // mode 0: stochastic (Sequoia), 1: token equality against tgt (greedy argmax or caller-supplied samples),
+    //      2: stochastic without the draft-logit side effects (SpecInfer)
     const VerifyWs ws = ws_layout(ws_raw, n_tree);
     if (threadIdx.x != 0) return;
+    const int greedy = mode == 1;
+    const int64_t* tgt = tgt_tokens ? tgt_tokens : ws.tgt;
     int node = 0, n_acc = 0, terminal = 0, reason = 0;
     for (int guard = 0; guard < n_tree; ++guard) {
         int child = -1, nrej = 0;
         const int c0 = child_off[node], nc = child_off[node + 1] - c0;
         if (greedy) {
-            const int64_t want = ws.tgt[node];
+            const int64_t want = tgt[node];
             for (int j = 0; j < nc; ++j) {
                 const int c = child_ids[c0 + j];
                 if (tokens[c + gt - 1] == want) { child = c; break; }
@@ -307,7 +323,7 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
             child = ws.child[node];
             nrej = ws.nrej[node];
             // draft_logits[node][token of every rejected child] = finfo(fp16).min
-            for (int j = 0; j < nrej && j < nc; ++j) {
+            for (int j = 0; mode == 0 && j < nrej && j < nc; ++j) {
                 const int64_t tok = tokens[child_ids[c0 + j] + gt - 1];
                 if (tok >= 0 && tok < vocab) draft_logits[(size_t)node * vocab + tok] = (half_t)(-65504.0f);
             }
@@ -324,7 +340,7 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
     int bonus = -1;
     if (!terminal) {
         if (greedy) {
-            bonus = (int)ws.tgt[node];
+            bonus = (int)tgt[node];
         } else if (ws.flag[node]) {
             terminal = 1; reason = 2;                                   // isnan(residual), :219
         } else {
@@ -333,9 +349,14 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
     }
     // tokens[:a] = tokens[accept_list]: slots ascending and dst <= src, so the sequential
     // in-place move never overwrites a source it still needs.
-    for (int j = 0; j < n_acc; ++j) tokens[gt + j] = tokens[ws.path[j] + gt - 1];
+    // Order of the two writes follows the reference: SpecTree / SpecInferTree store the bonus token at slot a
+    // BEFORE the gather (Tree/SpecTree.py:222-224), so an accepted node that happens to sit at slot a (tree node
+    // n_acc + 1 on the accepted path, e.g. a fully accepted 8x8 tree) is committed with the bonus token's id;
+    // GreedyTree / GreedySTree gather first (Tree/GreedyTree.py:204-206).  Reproduced for token parity.
     const int a = gt + n_acc;
-    if (!terminal) tokens[a] = bonus;
+    if (!greedy && !terminal) tokens[a] = bonus;
+    for (int j = 0; j < n_acc; ++j) tokens[gt + j] = tokens[ws.path[j] + gt - 1];
+    if (greedy && !terminal) tokens[a] = bonus;
     result[SQ_RES_ACCEPT_LEN] = a;
     result[SQ_RES_N_TREE] = n_acc;
     result[SQ_RES_BONUS] = bonus;
@@ -346,10 +367,10 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
     result[7] = 0;
 }
 
-extern "C" int sq_verify_stochastic_f16(const void* target_logits, void* draft_logits, int64_t* tokens, const void* r,
-                                        const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab,
-                                        int gt, float temperature, uint32_t bonus_u24, void* workspace,
-                                        int32_t* d_result, void* stream) {
+static int verify_stochastic_impl(const void* target_logits, void* draft_logits, int64_t* tokens, const void* r,
+                                  const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab, int gt,
+                                  float temperature, uint32_t bonus_u24, void* workspace, int32_t* d_result, void* stream,
+                                  bool replace) {
     if (!target_logits || !draft_logits || !tokens || !r || !d_child_off || !workspace || !d_result) return SQ_EINVAL;
     if (n_tree <= 0 || n_tree > SQ_MAX_TREE || vocab <= 0 || gt < 1 || !(temperature > 0.f)) return SQ_EINVAL;
     if (n_tree > 1 && !d_child_ids) return SQ_EINVAL;
@@ -357,18 +378,74 @@ extern "C" int sq_verify_stochastic_f16(const void* target_logits, void* draft_l
     if (bonus_u24 >= (1u << 24)) return SQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     dim3 g(n_tree), b(VER_THREADS);
-#define SQ_LAUNCH(EPT)                                                                                          \
-    hipLaunchKernelGGL((verify_nodes_kernel<EPT>), g, b, 0, st, (const half_t*)target_logits,                    \
+#define SQ_LAUNCH(EPT, REP)                                                                                     \
+    hipLaunchKernelGGL((verify_nodes_kernel<EPT, REP>), g, b, 0, st, (const half_t*)target_logits,               \
                        (const half_t*)draft_logits, (const int64_t*)tokens, (const half_t*)r, d_child_off,        \
                        d_child_ids, n_tree, vocab, gt, temperature, bonus_u24, workspace)
-    if (vocab <= 8 * VER_THREADS) SQ_LAUNCH(8);
-    else if (vocab <= 32 * VER_THREADS) SQ_LAUNCH(32);
+    if (vocab <= 8 * VER_THREADS) { if (replace) SQ_LAUNCH(8, true); else SQ_LAUNCH(8, false); }
+    else if (vocab <= 32 * VER_THREADS) { if (replace) SQ_LAUNCH(32, true); else SQ_LAUNCH(32, false); }
     else return SQ_EUNSUPPORTED;
 #undef SQ_LAUNCH
     int rc = sq_check_launch();
     if (rc != SQ_OK) return rc;
     hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, st, (half_t*)draft_logits, tokens, d_child_off,
-                       d_child_ids, n_tree, vocab, gt, workspace, d_result, 0);
+                       d_child_ids, n_tree, vocab, gt, workspace, d_result, replace ? 2 : 0, (const int64_t*)nullptr);
+    return sq_check_launch();
+}
+
+extern "C" int sq_verify_stochastic_f16(const void* target_logits, void* draft_logits, int64_t* tokens, const void* r,
+                                        const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab,
+                                        int gt, float temperature, uint32_t bonus_u24, void* workspace,
+                                        int32_t* d_result, void* stream) {
+    return verify_stochastic_impl(target_logits, draft_logits, tokens, r, d_child_off, d_child_ids, n_tree, vocab, gt,
+                                  temperature, bonus_u24, workspace, d_result, stream, false);
+}
+
+extern "C" int sq_verify_specinfer_f16(const void* target_logits, const void* draft_logits, int64_t* tokens, const void* r,
+                                       const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab,
+                                       int gt, float temperature, uint32_t bonus_u24, void* workspace,
+                                       int32_t* d_result, void* stream) {
+    return verify_stochastic_impl(target_logits, (void*)draft_logits, tokens, r, d_child_off, d_child_ids, n_tree, vocab,
+                                  gt, temperature, bonus_u24, workspace, d_result, stream, true);
+}
+
+// ---- i.i.d. draws from softmax(logits / T) (SpecInfer's draft expansion, Tree/SpecInferTree.py:104-109) ------------
+// One workgroup per row; draw j of row i is the exact inverse CDF at u24[i][j] / 2^24 (explicit uniforms replace
+// torch's device multinomial stream).  Output placement like sq_sample_wor_f16: branch / out_off gather.
+template <int EPT>
+__global__ void __launch_bounds__(VER_THREADS)
+sample_iid_kernel(const half_t* __restrict__ logits, int64_t ld, const int32_t* __restrict__ row_ids, int vocab, int k,
+                  float temperature, const uint32_t* __restrict__ u24, int64_t* __restrict__ out,
+                  const int32_t* __restrict__ branch, const int32_t* __restrict__ out_off) {
+    __shared__ float s_f[VER_WAVES];
+    const int t = threadIdx.x, row = blockIdx.x;
+    const int src = row_ids ? row_ids[row] : row;
+    half_t p[EPT];
+    row_softmax_f16<EPT>(logits + (size_t)src * ld, vocab, temperature, t, p, s_f);
+    const int take = branch ? branch[row] : k;
+    const int64_t base = out_off ? (int64_t)out_off[row] : (int64_t)row * k;
+    for (int j = 0; j < take; ++j) {
+        const int tok = block_inverse_cdf<EPT>(p, vocab, t, u24[(size_t)row * k + j] & 0xffffffu);
+        if (t == 0) out[base + j] = tok;
+    }
+}
+
+extern "C" int sq_sample_iid_f16(const void* logits, int64_t ld, const int32_t* d_row_ids, int n_rows, int vocab, int k,
+                                 float temperature, const uint32_t* d_u24, int64_t* d_out, const int32_t* d_branch,
+                                 const int32_t* d_out_off, void* stream) {
+    if (!logits || !d_u24 || !d_out || n_rows < 0 || vocab <= 0 || k <= 0 || ld < vocab || !(temperature > 0.f)) return SQ_EINVAL;
+    if ((vocab & 7) || (ld & 7) || ((uintptr_t)logits & 15)) return SQ_EUNSUPPORTED;
+    if (n_rows == 0) return SQ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(n_rows), b(VER_THREADS);
+    if (vocab <= 8 * VER_THREADS)
+        hipLaunchKernelGGL((sample_iid_kernel<8>), g, b, 0, st, (const half_t*)logits, ld, d_row_ids, vocab, k, temperature,
+                           d_u24, d_out, d_branch, d_out_off);
+    else if (vocab <= 32 * VER_THREADS)
+        hipLaunchKernelGGL((sample_iid_kernel<32>), g, b, 0, st, (const half_t*)logits, ld, d_row_ids, vocab, k, temperature,
+                           d_u24, d_out, d_branch, d_out_off);
+    else
+        return SQ_EUNSUPPORTED;
     return sq_check_launch();
 }
 
@@ -534,6 +611,19 @@ extern "C" int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens, 
     int rc = sq_check_launch();
     if (rc != SQ_OK) return rc;
     hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, st, (half_t*)nullptr, tokens, d_child_off, d_child_ids,
-                       n_tree, vocab, gt, workspace, d_result, 1);
+                       n_tree, vocab, gt, workspace, d_result, 1, (const int64_t*)nullptr);
+    return sq_check_launch();
+}
+
+// token-equality walk against caller-supplied target tokens (GreedySTree: one token SAMPLED per node from the
+// target distribution instead of the argmax, Tree/GreedySTree.py:188-190,196-214)
+extern "C" int sq_verify_tokens_f16(const int64_t* d_target_tokens, int64_t* tokens, const int32_t* d_child_off,
+                                    const int32_t* d_child_ids, int n_tree, int gt, void* workspace, int32_t* d_result,
+                                    void* stream) {
+    if (!d_target_tokens || !tokens || !d_child_off || !workspace || !d_result) return SQ_EINVAL;
+    if (n_tree <= 0 || n_tree > SQ_MAX_TREE || gt < 1) return SQ_EINVAL;
+    if (n_tree > 1 && !d_child_ids) return SQ_EINVAL;
+    hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (half_t*)nullptr, tokens, d_child_off,
+                       d_child_ids, n_tree, 0, gt, workspace, d_result, 1, d_target_tokens);
     return sq_check_launch();
 }

@@ -25,6 +25,8 @@ _ALIASES = {
     "Tree.Tree": "sequoia_amd.Tree.Tree",
     "Tree.SpecTree": "sequoia_amd.Tree.SpecTree",
     "Tree.GreedyTree": "sequoia_amd.Tree.GreedyTree",
+    "Tree.SpecInferTree": "sequoia_amd.Tree.SpecInferTree",
+    "Tree.GreedySTree": "sequoia_amd.Tree.GreedySTree",
     "utils": "sequoia_amd.utils",
 }
 

@@ -40,6 +40,9 @@ PROTOTYPES = {
     "sq_sample_wor_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "sq_topk_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "sq_verify_workspace_bytes": (C.c_size_t, [_i]),
+    "sq_sample_iid_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "sq_verify_specinfer_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp]),
+    "sq_verify_tokens_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "sq_verify_stochastic_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp]),
     "sq_top_p_filter_f16": (_i, [_vp, _i64, _i, _i, _f, _f, _vp]),
     "sq_verify_greedy_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

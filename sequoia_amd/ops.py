@@ -192,6 +192,42 @@ class HipOps:
                                                 self._stream()), "sq_verify_stochastic_f16")
         return result
 
+    def sample_iid(self, logits, u24, row_ids, k, temperature, out, branch=None, out_off=None):
+        """k draws with replacement per row of softmax(logits / T); u24: int32 [n_rows, k] uniforms in [0, 2^24)."""
+        _need(logits, torch.float16, "logits", contiguous=False); _need(u24, torch.int32, "u24")
+        assert logits.stride(1) == 1
+        _need(out, torch.int64, "out", contiguous=False)
+        n_rows = row_ids.shape[0] if row_ids is not None else logits.shape[0]
+        assert u24.numel() >= n_rows * k
+        if row_ids is not None:
+            _need(row_ids, torch.int32, "row_ids")
+        check(self.lib.sq_sample_iid_f16(logits.data_ptr(), logits.stride(0), _ptr(row_ids), n_rows, logits.shape[1], k,
+                                         float(temperature), u24.data_ptr(), out.data_ptr(), _ptr(branch), _ptr(out_off),
+                                         self._stream()), "sq_sample_iid_f16")
+        return out
+
+    def verify_specinfer(self, target_logits, draft_logits, tokens, r, child_off, child_ids, n_tree, gt, temperature,
+                         u24, workspace, result):
+        _need(target_logits, torch.float16, "target_logits"); _need(draft_logits, torch.float16, "draft_logits")
+        _need(tokens, torch.int64, "tokens"); _need(r, torch.float16, "r")
+        _need(child_off, torch.int32, "child_off"); _need(result, torch.int32, "result")
+        vocab = target_logits.shape[-1]
+        assert draft_logits.shape[-1] == vocab and target_logits.shape[0] >= n_tree and draft_logits.shape[0] >= n_tree
+        check(self.lib.sq_verify_specinfer_f16(target_logits.data_ptr(), draft_logits.data_ptr(), tokens.data_ptr(),
+                                               r.data_ptr(), child_off.data_ptr(), _ptr(child_ids), n_tree, vocab, gt,
+                                               float(temperature), int(u24), workspace.data_ptr(), result.data_ptr(),
+                                               self._stream()), "sq_verify_specinfer_f16")
+        return result
+
+    def verify_tokens(self, target_tokens, tokens, child_off, child_ids, n_tree, gt, workspace, result):
+        _need(target_tokens, torch.int64, "target_tokens"); _need(tokens, torch.int64, "tokens")
+        _need(child_off, torch.int32, "child_off"); _need(result, torch.int32, "result")
+        assert target_tokens.numel() >= n_tree
+        check(self.lib.sq_verify_tokens_f16(target_tokens.data_ptr(), tokens.data_ptr(), child_off.data_ptr(),
+                                            _ptr(child_ids), n_tree, gt, workspace.data_ptr(), result.data_ptr(),
+                                            self._stream()), "sq_verify_tokens_f16")
+        return result
+
     def top_p_filter(self, logits, top_p, temperature):
         """In-place nucleus filter on 2-D fp16 logits rows."""
         _need(logits, torch.float16, "logits", contiguous=False)

@@ -24,6 +24,7 @@ def load_trace(name):
 
 TRACE_NAMES = ["A_2chain", "B_seq128", "demo4", "C_greedy8x8", "E_64x2"]
 STOCHASTIC_TRACES = ["A_2chain", "B_seq128", "demo4", "E_64x2"]
+BASELINE_TRACES = ["F_specinfer", "G_greedys"]        # the paper's comparison baselines (SpecInferTree, GreedySTree)
 
 
 @pytest.fixture(scope="session")

@@ -38,7 +38,10 @@ def make_tree(z, meta, draft, target, device, cls=None):
     from sequoia_amd.Tree.SpecTree import SpecTree
     M = meta["M"]
     g = GrowMap.from_successors(meta["successors"]).to_reference_dict()
-    cls = cls or (SpecTree if meta["mode"] == "stochastic" else GreedyTree)
+    if cls is None:
+        from sequoia_amd.Tree.GreedySTree import GreedySTree
+        from sequoia_amd.Tree.SpecInferTree import SpecInferTree
+        cls = {"stochastic": SpecTree, "greedy": GreedyTree, "specinfer": SpecInferTree, "greedys": GreedySTree}[meta["mode"]]
     torch.manual_seed(meta["seed"] + 7)          # same noise seed as oracle/gen_golden.py
     tree = cls(prefix=torch.from_numpy(z["prompt"]), device=device, temperature=meta["T"], top_p=1.0, draft_kv_len=0,
                target_kv_len=0, draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
@@ -47,6 +50,10 @@ def make_tree(z, meta, draft, target, device, cls=None):
                position_ids=torch.zeros(M, device=device).long(), residual_graph=None, sampling_callables=None,
                sample_gather_indices=None, vocab_size=meta["vocab"],
                bonus_uniforms=[int(x) for x in z["bonus_u24"]])
+    if meta["mode"] == "specinfer":
+        tree.draw_uniforms = [z["draw_u24"][i] for i in range(z["draw_u24"].shape[0])]     # the trace's uniforms, per step
+    if meta["mode"] == "greedys":
+        tree.target_uniforms = [z["target_u24"][i] for i in range(z["target_u24"].shape[0])]
     return tree
 
 
@@ -107,6 +114,6 @@ def check_replay(steps, z, meta, logit_tol=4e-2):
         assert dd <= logit_tol and dt <= logit_tol, f"step {s}: logits off by {dd:.4f} / {dt:.4f}"
         if rec["accept_len"] == rec["ref_accept_len"] and np.array_equal(rec["valid"], rec["ref_valid"]):
             continue
-        assert meta["mode"] == "stochastic", f"greedy step {s} must be bit-exact"
+        assert meta["mode"] != "greedy", f"greedy step {s} must be bit-exact"
         return s, s
     return len(steps), None
