@@ -179,11 +179,15 @@ size_t sq_verify_workspace_bytes(int n_tree);
  *   terminal (reason 2); otherwise the bonus token is drawn from the residual by exact
  *   inverse-CDF with the caller's 24-bit uniform `bonus_u24` (replaces multinomial(1), :222).
  * Side effects (all in device memory, no host sync):
- *   tokens[gt .. a) = tokens[accepted slots], tokens[a] = bonus           (:224, :222)
+ *   tokens[a] = bonus, THEN tokens[gt .. a) = tokens[accepted slots]      (:222, :224 -- the reference's
+ *     order: an accepted node sitting at slot a, i.e. tree node n_accepted + 1 on the accepted path, is
+ *     committed with the bonus token's id.  OR SQ_VERIFY_GATHER_FIRST into bonus_u24 for the lossless
+ *     order: gather first, then the bonus write)
  *   draft_logits rows of the walked nodes get the -65504 writes           (:156)
  *   result record filled (see SQ_RES_*).
  * target_logits: fp16 [n_tree][V]; draft_logits: fp16 [>= n_tree][V] (tree-local rows);
  * tokens: int64 [M]; r: fp16 [M]; children CSR over tree-local ids.                          */
+#define SQ_VERIFY_GATHER_FIRST 0x80000000u
 int sq_verify_stochastic_f16(const void* target_logits, void* draft_logits,
                              int64_t* tokens, const void* r,
                              const int32_t* d_child_off, const int32_t* d_child_ids,

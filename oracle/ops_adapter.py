@@ -113,7 +113,7 @@ class OracleOps:
                           u24, workspace, result):
         succ = _succ_from_csr(child_off, child_ids, n_tree)
         res = O.verify_stochastic(_np(target_logits), _np(draft_logits), _np(tokens), _np(r), succ, gt, temperature,
-                                  int(u24))
+                                  int(u24) & 0xffffff, gather_first=bool(int(u24) & 0x80000000))
         self._fill(result, res)
         return result
 
@@ -126,8 +126,8 @@ class OracleOps:
     def verify_specinfer(self, target_logits, draft_logits, tokens, r, child_off, child_ids, n_tree, gt, temperature,
                          u24, workspace, result):
         succ = _succ_from_csr(child_off, child_ids, n_tree)
-        res = O.verify_specinfer(_np(target_logits), _np(draft_logits), _np(tokens), _np(r), succ, gt, temperature,
-                                 int(u24))
+        res = O.verify_stochastic(_np(target_logits), _np(draft_logits), _np(tokens), _np(r), succ, gt, temperature,
+                                  int(u24) & 0xffffff, replace=True, gather_first=bool(int(u24) & 0x80000000))
         self._fill(result, res)
         return result
 

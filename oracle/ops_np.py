@@ -297,7 +297,7 @@ def accept_children(p16, draft_row16, child_tokens, child_r16, temperature, marg
 
 
 def verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, gt, temperature,
-                      u24, margins=None, replace=False):
+                      u24, margins=None, replace=False, gather_first=False):
     """SpecTree.verify from the softmax to the token compaction (Tree/SpecTree.py:196-224).
 
     target_logits16: [n, V]; draft_logits16: [>=n, V] tree-local rows (mutated); tokens: int64[M]
@@ -333,10 +333,13 @@ def verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, 
                 terminal, reason = True, 2
     # the reference stores the bonus token BEFORE the gather (Tree/SpecTree.py:222-224): an accepted node sitting at
     # slot a is therefore committed with the bonus token's id (quirk reproduced for token parity)
-    if not terminal:
+    # (gather_first = the lossless order, SQ_VERIFY_GATHER_FIRST)
+    if not terminal and not gather_first:
         tokens[a] = bonus
     if slots:
         tokens[gt:a] = tokens[np.asarray(slots)].copy()
+    if not terminal and gather_first:
+        tokens[a] = bonus
     return dict(accept_len=a, n_tree=len(slots), bonus=bonus, terminal=int(terminal), reason=reason,
                 gt=gt, last_node=node, slots=slots, final_p=p)
 

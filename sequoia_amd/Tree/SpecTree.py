@@ -33,4 +33,4 @@ class SpecTree(NativeTree):
             self.ops.top_p_filter(self.target_logits, self.top_p, self.temperature)
         self.ops.verify_stochastic(self.target_logits, self.draft_logits, self.tokens, self.r, self.gdev["child_off"],
                                    self.gdev["child_ids"], self.tree_size, gt, self.temperature,
-                                   self.bonus_u24[self.step_idx % len(self.bonus_u24)], self.verify_ws, self.result)
+                                   self._bonus_uniform(), self.verify_ws, self.result)

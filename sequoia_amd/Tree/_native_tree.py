@@ -11,12 +11,13 @@ API must return the accepted length to the caller); everything else is stream-or
 """
 from __future__ import annotations
 
+import os
 import time
 
 import torch
 
 from ..Engine.Llama_modules import TreeContext
-from ..native import (SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_SLOTS, SQ_RES_TERMINAL, SQ_RESULT_INTS)
+from ..native import (SQ_VERIFY_GATHER_FIRST, SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_SLOTS, SQ_RES_TERMINAL, SQ_RESULT_INTS)
 from ..ops import get_ops
 from .Tree import Tree, growmap_on_device
 
@@ -24,6 +25,13 @@ from .Tree import Tree, growmap_on_device
 def _sync(device):
     if str(device).startswith("cuda"):
         torch.cuda.synchronize()
+
+
+# SpecTree / SpecInferTree commit order.  "reference" (default): bonus token stored before the accepted tokens are
+# gathered, like Tree/SpecTree.py:222-224 -- token parity with the reference, including its quirk that an accepted node
+# sitting at slot gt + n_accepted (e.g. the root's second child accepted alone) is committed with the bonus token's id.
+# "lossless": gather first, so the committed tokens are exactly the accepted ones (the algorithm as published).
+COMMIT_ORDER = os.environ.get("SEQUOIA_COMMIT_ORDER", "reference")
 
 
 class NativeTree(Tree):
@@ -88,6 +96,7 @@ class NativeTree(Tree):
             self.bonus_u24 = [int(x) for x in bonus_uniforms]
         self.step_idx = 0
         self._no_room = None
+        self.commit_order = COMMIT_ORDER
         self.verify_ws = self.ops.verify_workspace(n, self.device)
         self.result = torch.zeros(SQ_RESULT_INTS + n, dtype=torch.int32, device=self.device)
         self.seq_to_use = list(range(self.max_length))
@@ -109,6 +118,10 @@ class NativeTree(Tree):
 
     def _verify_native(self, gt: int):
         raise NotImplementedError
+
+    def _bonus_uniform(self) -> int:
+        u = self.bonus_u24[self.step_idx % len(self.bonus_u24)]
+        return u | SQ_VERIFY_GATHER_FIRST if self.commit_order == "lossless" else u
 
     # ---- draft expansion --------------------------------------------------------------------------
     @torch.inference_mode()

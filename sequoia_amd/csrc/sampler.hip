@@ -40,6 +40,14 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
     if (WOR) {
         float y[EPT];
         float lmax = -INFINITY;
+        // the noise row is fetched together with the logits row: one HBM latency instead of two
+        const half_t* u = rnd + row * ld_rand;
+        half8 uv[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int e0 = elem_index(c, t, 0);
+            if (e0 < vocab) uv[c] = *(const half8*)(u + e0);
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int e0 = elem_index(c, t, 0);
@@ -61,16 +69,12 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
             lsum += y[i];
         }
         const float z = block_sum_f32<SAMP_WAVES>(lsum, s_f);
-        const half_t* u = rnd + row * ld_rand;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int e0 = elem_index(c, t, 0);
-            half8 uv;
-            if (e0 < vocab) uv = *(const half8*)(u + e0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const half_t q = (half_t)div_rn(y[c * 8 + j], z);
-                const half_t lu = (half_t)log_fast((float)uv[j]);
+                const half_t lu = (half_t)log_fast((float)uv[c][j]);
                 // lu / 0 = -inf (lu < 0 always: u < 1); otherwise the correctly rounded quotient
                 key[c * 8 + j] = (q == (half_t)0.0f) ? (half_t)(-INFINITY) : (half_t)div_rn((float)lu, (float)q);
             }

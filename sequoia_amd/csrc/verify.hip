@@ -307,7 +307,9 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
     //      2: stochastic without the draft-logit side effects (SpecInfer)
     const VerifyWs ws = ws_layout(ws_raw, n_tree);
     if (threadIdx.x != 0) return;
-    const int greedy = mode == 1;
+    const int greedy = (mode & 3) == 1;
+    const int gather_first = greedy || (mode & 4);
+    mode &= 3;
     const int64_t* tgt = tgt_tokens ? tgt_tokens : ws.tgt;
     int node = 0, n_acc = 0, terminal = 0, reason = 0;
     for (int guard = 0; guard < n_tree; ++guard) {
@@ -352,11 +354,12 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
     // Order of the two writes follows the reference: SpecTree / SpecInferTree store the bonus token at slot a
     // BEFORE the gather (Tree/SpecTree.py:222-224), so an accepted node that happens to sit at slot a (tree node
     // n_acc + 1 on the accepted path, e.g. a fully accepted 8x8 tree) is committed with the bonus token's id;
-    // GreedyTree / GreedySTree gather first (Tree/GreedyTree.py:204-206).  Reproduced for token parity.
+    // GreedyTree / GreedySTree gather first (Tree/GreedyTree.py:204-206).  Reproduced for token parity; callers that
+    // want the lossless order pass SQ_VERIFY_GATHER_FIRST with the bonus uniform.
     const int a = gt + n_acc;
-    if (!greedy && !terminal) tokens[a] = bonus;
+    if (!gather_first && !terminal) tokens[a] = bonus;
     for (int j = 0; j < n_acc; ++j) tokens[gt + j] = tokens[ws.path[j] + gt - 1];
-    if (greedy && !terminal) tokens[a] = bonus;
+    if (gather_first && !terminal) tokens[a] = bonus;
     result[SQ_RES_ACCEPT_LEN] = a;
     result[SQ_RES_N_TREE] = n_acc;
     result[SQ_RES_BONUS] = bonus;
@@ -375,6 +378,8 @@ static int verify_stochastic_impl(const void* target_logits, void* draft_logits,
     if (n_tree <= 0 || n_tree > SQ_MAX_TREE || vocab <= 0 || gt < 1 || !(temperature > 0.f)) return SQ_EINVAL;
     if (n_tree > 1 && !d_child_ids) return SQ_EINVAL;
     if ((vocab & 7) || ((uintptr_t)target_logits & 15) || ((uintptr_t)draft_logits & 15)) return SQ_EUNSUPPORTED;
+    const int gather_first = (bonus_u24 & SQ_VERIFY_GATHER_FIRST) ? 4 : 0;
+    bonus_u24 &= ~SQ_VERIFY_GATHER_FIRST;
     if (bonus_u24 >= (1u << 24)) return SQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     dim3 g(n_tree), b(VER_THREADS);
@@ -389,7 +394,8 @@ static int verify_stochastic_impl(const void* target_logits, void* draft_logits,
     int rc = sq_check_launch();
     if (rc != SQ_OK) return rc;
     hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, st, (half_t*)draft_logits, tokens, d_child_off,
-                       d_child_ids, n_tree, vocab, gt, workspace, d_result, replace ? 2 : 0, (const int64_t*)nullptr);
+                       d_child_ids, n_tree, vocab, gt, workspace, d_result, (replace ? 2 : 0) | gather_first,
+                       (const int64_t*)nullptr);
     return sq_check_launch();
 }
 

@@ -18,6 +18,7 @@ SQ_RESULT_INTS = 64
 SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_BONUS, SQ_RES_TERMINAL = 0, 1, 2, 3
 SQ_RES_REASON, SQ_RES_GT, SQ_RES_LAST_NODE, SQ_RES_SLOTS = 4, 5, 6, 8
 SQ_ATT_OUT_FRAG = 0x100
+SQ_VERIFY_GATHER_FIRST = 0x80000000
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 

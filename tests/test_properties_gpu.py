@@ -28,7 +28,11 @@ def dev(a):
 
 
 def test_verifier_is_lossless_in_distribution(ops):
-    """chi-square of the first emitted token against p, 24k trials, V = 16, root with 3 children."""
+    """chi-square of the first emitted token against p, 24k trials, V = 16, root with 3 children.  Run with the
+    lossless commit order (SQ_VERIFY_GATHER_FIRST): in the reference's order (the default, for token parity) the
+    root's second child accepted alone is committed with the bonus token's id, which biases exactly this statistic
+    (test_reference_commit_order_quirk below)."""
+    from sequoia_amd.native import SQ_VERIFY_GATHER_FIRST
     V, n, gt, T = 16, 4, 5, 1.0
     succ_off = np.array([0, 3, 3, 3, 3], dtype=np.int32)
     succ_ids = np.array([1, 2, 3], dtype=np.int32)
@@ -58,7 +62,7 @@ def test_verifier_is_lossless_in_distribution(ops):
     for i in range(trials):
         d_dl = d_dl0.clone()                         # the verifier writes -65504 into rejected entries
         ops.sample_wor(d_dl, rand_all[i:i + 1], row0, 3, T, tokens[gt:], branch=branch, out_off=out_off)
-        ops.verify_stochastic(d_tl, d_dl, tokens, r_all[i], d_off, d_ids, n, gt, T, u_all[i], ws, res)
+        ops.verify_stochastic(d_tl, d_dl, tokens, r_all[i], d_off, d_ids, n, gt, T, u_all[i] | SQ_VERIFY_GATHER_FIRST, ws, res)
         first[i] = tokens[gt]                        # first accepted child, or the bonus token
     counts = np.bincount(first.cpu().numpy(), minlength=V).astype(np.float64)
     exp = p * trials
@@ -68,6 +72,32 @@ def test_verifier_is_lossless_in_distribution(ops):
     # 99.9% quantile of chi2(dof<=15) is < 38; a biased verifier (e.g. >= instead of >, or a
     # residual without renormalisation) lands in the hundreds
     assert chi2 < 45, (chi2, dof, counts, exp)
+
+
+def test_reference_commit_order_quirk(ops):
+    """Tree/SpecTree.py:222-224 stores the bonus token at slot a = gt + n_accepted before gathering the accepted
+    tokens.  Root with 3 children, the SECOND child accepted alone: its slot is a, so the reference commits the bonus
+    token twice.  The default order reproduces that (token parity); SQ_VERIFY_GATHER_FIRST commits the accepted token."""
+    from oracle import ops_np as O
+    from sequoia_amd.native import SQ_VERIFY_GATHER_FIRST
+    V, n, gt, T = 64, 4, 7, 1.0
+    off, ids = np.array([0, 3, 3, 3, 3], np.int32), np.array([1, 2, 3], np.int32)
+    tl = np.full((n, V), -8.0, np.float16); dl = np.zeros((n, V), np.float16)
+    tl[0, 11] = 8.0                       # the target wants token 11 at the root ...
+    tl[2, 30] = 8.0                       # ... and token 30 after it
+    tokens0 = np.zeros(16, np.int64); tokens0[gt:gt + 3] = [5, 11, 9]     # child 1 wrong, child 2 right
+    r = np.full(16, 0.5, np.float16)
+    for flag, want in ((0, [30, 30]), (SQ_VERIFY_GATHER_FIRST, [11, 30])):
+        tokens = dev(tokens0.copy())
+        ws = ops.verify_workspace(n, DEV)
+        res = torch.zeros(64 + n, dtype=torch.int32, device=DEV)
+        ops.verify_stochastic(dev(tl), dev(dl.copy()), tokens, dev(r), dev(off), dev(ids), n, gt, T, 12345 | flag, ws, res)
+        rr = res.cpu().numpy()
+        assert rr[0] == gt + 1 and rr[1] == 1 and rr[8] == gt + 1 and rr[2] == 30
+        assert tokens.cpu().numpy()[gt:gt + 2].tolist() == want
+        o_tok = tokens0.copy()
+        O.verify_stochastic(tl, dl.copy(), o_tok, r, [[1, 2, 3], [], [], []], gt, T, 12345, gather_first=bool(flag))
+        assert o_tok[gt:gt + 2].tolist() == want
 
 
 @pytest.mark.parametrize("mode", ["stochastic", "greedy"])
