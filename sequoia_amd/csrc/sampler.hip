@@ -101,24 +101,44 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
         // composites are built once; a retired element becomes 0 and each round is one
         // compare-select-max sweep over the thread's registers
         uint32_t comp[EPT];
+        uint32_t gmax[CH];                               // running maximum of every 8-element chunk
         uint32_t best = 0u;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int e = elem_index(i >> 3, t, i & 7);
-            comp[i] = (e < vocab) ? ((f16_to_ordered(key[i]) << 16) | (0xffffu - (uint32_t)e)) : 0u;
-            best = comp[i] > best ? comp[i] : best;
+        for (int c = 0; c < CH; ++c) {
+            uint32_t m = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = elem_index(c, t, j);
+                const uint32_t v = (e < vocab) ? ((f16_to_ordered(key[c * 8 + j]) << 16) | (0xffffu - (uint32_t)e)) : 0u;
+                comp[c * 8 + j] = v;
+                m = v > m ? v : m;
+            }
+            gmax[c] = m;
+            best = m > best ? m : best;
         }
         for (int s = 0; s < n_out; ++s) {
-            const uint32_t win = wave_max_u32_dpp(best);
+            const uint32_t win = wave_max_u32_dpp(best);  // wave-uniform (SGPR)
             if (lane == 0) s_cand[wave * SQ_MAX_TOPK + s] = win;
-            if (win == best && win != 0u) {          // this lane owns the winner (composites are unique)
-                best = 0u;
+            if (win == 0u) continue;
+            // the winner's chunk follows from its token id: only that chunk is rescanned (a scalar branch per
+            // chunk, the id is wave-uniform), and only in the lane that owns it
+            const int wc = (int)(((0xffffu - (win & 0xffffu)) >> 3) / SAMP_THREADS);
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) {
-                    comp[i] = (comp[i] == win) ? 0u : comp[i];
-                    best = comp[i] > best ? comp[i] : best;
+            for (int c = 0; c < CH; ++c) {
+                if (c == wc) {
+                    uint32_t m = 0u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t v = (comp[c * 8 + j] == win) ? 0u : comp[c * 8 + j];
+                        comp[c * 8 + j] = v;
+                        m = v > m ? v : m;
+                    }
+                    gmax[c] = m;
                 }
             }
+            best = 0u;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) best = gmax[c] > best ? gmax[c] : best;
         }
         __syncthreads();
         if (wave == 0) {
@@ -134,6 +154,7 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
             uint32_t lb = 0u;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) lb = c[j] > lb ? c[j] : lb;
+            const int used = (total + 63) >> 6;            // candidate registers that hold anything (5 of 32 for k = 19)
             for (int s = 0; s < n_out; ++s) {
                 const uint32_t win = wave_max_u32_dpp(lb);
                 if (lane == 0) dst[s] = (win == 0u) ? 0 : (int64_t)(0xffffu - (win & 0xffffu));
@@ -141,8 +162,10 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
                     lb = 0u;
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) {
-                        if (c[j] == win) c[j] = 0u;
-                        lb = c[j] > lb ? c[j] : lb;
+                        if (j < used) {
+                            if (c[j] == win) c[j] = 0u;
+                            lb = c[j] > lb ? c[j] : lb;
+                        }
                     }
                 }
             }
