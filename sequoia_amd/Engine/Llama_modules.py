@@ -4,7 +4,8 @@ The reference implements these as nn.Modules on HF internals (Engine/Llama_modul
 they are plain functions over a fused-weight layer record, with the hot ops in HIP:
 RMSNorm(+residual) -> sq_(add_)rmsnorm_f16, RoPE + KV slot write -> sq_rope_kv_write_f16,
 tree-batched attention -> sq_tree_attention_f16, SwiGLU gate -> sq_silu_mul_f16.  The dense
-projections stay on PyTorch (hipBLASLt) as BASELINE.json's north_star prescribes.
+projections in THIS module are PyTorch's (hipBLASLt): it serves prompt prefill (> 128 rows) and
+tensor-parallel shards; tree forwards of <= 128 rows run Engine/ts_linear.py instead.
 """
 from __future__ import annotations
 

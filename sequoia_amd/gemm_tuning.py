@@ -1,6 +1,7 @@
 """GEMM algorithm selection for the dense projections.
 
-The projections stay on PyTorch-ROCm (BASELINE.json north_star); what can be chosen is *which*
+For the projections that stay on PyTorch-ROCm (prompt prefill, tensor-parallel shards, and the few tree-forward
+shapes where hipBLASLt beats the tall-skinny kernel, Engine/ts_linear.py) what can be chosen is *which*
 hipBLASLt / rocBLAS solution PyTorch dispatches for each (M, N, K).  The library heuristics pick
 tiles that leave CUs idle for the skinny verify shapes (M = tree size 128, N = 4096: o_proj and
 down_proj run at 1.4-1.5 TB/s of weight streaming); PyTorch's TunableOp times the candidate
