@@ -240,3 +240,30 @@ def test_plan_candidates_respect_kernel_limits():
             per = (units + tiles - 1) // tiles
             assert per <= ((3 if m <= 64 else 2) if silu else 4)
             assert k // 32 >= splits * 8 and (splits == 1 or not silu)
+
+
+def test_tensor_parallel_hooks_disable_the_tall_skinny_path(monkeypatch):
+    """The TP engine attaches its all-reduce / vocab-gather hooks after the model is built; a forward with hooks must
+    stay on the general path (row-parallel partial sums need the reduction between o_proj / down_proj and the add)."""
+    from sequoia_amd.Engine import Llama_model
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine
+    from sequoia_amd.Engine.Llama_model import LlamaDims, LlamaWeights
+    from sequoia_amd.Engine.Llama_modules import TreeContext
+    cfg = dict(vocab_size=2048, hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+               num_key_value_heads=2, max_position_embeddings=2048)
+    W = LlamaWeights.random(LlamaDims.from_any(cfg), torch.float16, DEV, 2)
+    eng = GraphInferenceEngine(max_length=128, model_name_or_path={"weights": W}, dtype=torch.float16, device=DEV)
+    model = eng.engine.model
+    assert model.ts is not None
+    calls = []
+    model.reduce_fn = lambda t: (calls.append(1), t)[1]
+
+    def boom(*a, **k):
+        raise AssertionError("tall-skinny path taken with TP hooks attached")
+    monkeypatch.setattr(Llama_model, "forward_ts", boom)
+    ids = torch.randint(3, 2048, (1, 20), device=DEV)
+    ar = torch.arange(20, device=DEV)
+    bm = torch.ones((1, 1), dtype=torch.int64, device=DEV)
+    eng.inference(input_ids=ids, storage_ids=ar, position_ids=ar[None], attn_mask=None,
+                  tree=TreeContext(q_slot0=0, gt=20, n_tree=1, bitmask=bm, kv_len=20, contiguous_slots=True))
+    assert len(calls) == 4          # o_proj and down_proj of both layers went through the hook
