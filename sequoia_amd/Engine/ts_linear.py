@@ -230,7 +230,6 @@ def forward_ts(model, ts: TsLinearSet, x, q_len, pos, storage_ids, dense, tree, 
     plan = ts.plan(q_len)
     dev, dt = x.device, x.dtype
     hidden = dims.hidden_size
-    n_qkv, _, _ = ts.shapes["qkv"]
     inter = ts.shapes["down"][1]
     vocab = ts.shapes["lm_head"][0]
     fs = ops.frag_shape
@@ -250,8 +249,9 @@ def forward_ts(model, ts: TsLinearSet, x, q_len, pos, storage_ids, dense, tree, 
             ops.add_rmsnorm(pending[1], x, x, weight, out, eps)
         return out
 
-    def project(name, li, a, a_is_frag):
-        """One projection with output to rows or slabs.  Returns the pending record."""
+    def project(name, li, a):
+        """One projection (a: fragment-major when the plan uses the kernel, row-major otherwise) with output to rows
+        or split-K slabs.  Returns the pending record."""
         p = plan[name]
         n_out, k, _ = ts.shapes[name]
         if p is None:
@@ -267,10 +267,10 @@ def forward_ts(model, ts: TsLinearSet, x, q_len, pos, storage_ids, dense, tree, 
     pending = None
     for li, lw in enumerate(W.layers):
         h = norm_into(pending, lw.ln1, plan["qkv"] is not None)
-        qkv = project("qkv", li, h, plan["qkv"] is not None)[1]
+        qkv = project("qkv", li, h)[1]
         attn = attention_core(qkv, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
                               out_frag=plan["o"] is not None)
-        pending = project("o", li, attn, plan["o"] is not None)
+        pending = project("o", li, attn)
         h = norm_into(pending, lw.ln2, plan["gate_up"] is not None)
         down_ts = plan["down"] is not None
         act = torch.empty(fs(q_len, inter) if down_ts else (q_len, inter), dtype=dt, device=dev)
@@ -283,7 +283,7 @@ def forward_ts(model, ts: TsLinearSet, x, q_len, pos, storage_ids, dense, tree, 
                 ops.silu_mul_frag(gu, act, q_len, inter)
             else:
                 ops.silu_mul(gu, act)
-        pending = project("down", li, act, down_ts)
+        pending = project("down", li, act)
     h = norm_into(pending, W.norm, plan["lm_head"] is not None)
     kv_cache.note_written(q_len)
     if plan["lm_head"] is not None:
