@@ -190,8 +190,10 @@ extern "C" size_t sq_linear_ts_workspace_bytes(int m, int n_out, int splits) {
 template <int MT, int NT, bool SILU>
 static void ts_go(const TsParams& P, hipStream_t st) {
     // ring depth: the vmcnt counter tracks 63 loads, so D (NT + MT) must stay below.  Measured on MI355X: deeper
-    // rings (up to 8) and 8-wave workgroups are no faster -- the stream is bound by the CU's vector-memory ingest
-    // (~14 B/clk/CU for weights + activations together), not by bytes in flight.
+    // rings (up to 8), 8-wave workgroups, and both operands through LDS-DMA (global_load_lds_dwordx4 into a
+    // wave-private LDS ring, hand-counted waits: 27.6 vs 29.6 us on the 128-row qkv, 64 vs 62 us on gate_up) are no
+    // faster -- the stream is bound by the CU's memory ingest (~14 B/clk/CU for weights + activations together),
+    // not by bytes in flight or by the VGPR return path.
     constexpr int D = (MT * NT > 24) ? 3 : 4;
     const size_t lds = (size_t)TS_WAVES * MT * 16 * (NT * 16 + 4) * sizeof(float);
     auto kern = ts_linear_kernel<MT, NT, D, SILU>;
