@@ -24,3 +24,28 @@ class GreedyTree(NativeTree):
     def _verify_native(self, gt: int):
         self.ops.verify_greedy(self.target_logits, self.tokens, self.gdev["child_off"], self.gdev["child_ids"],
                                self.tree_size, gt, self.verify_ws, self.result)
+
+
+class GreedyTreeTest(GreedyTree):
+    """GreedyTree on a star growmap of `max_width` children (reference: Tree/GreedyTree.py:267-456, used by
+    tests/test_accept.py to measure which of the top-k draft tokens the target picks); verify() also returns b."""
+
+    def __init__(self, draft_model_engine, target_model_engine, prefix, temperature: float = 0.6, top_p: float = 0.9,
+                 draft_kv_len=0, target_kv_len=0, max_length=256, max_width=32, device="cpu", attn_mask=None,
+                 sequence=None, new_tokens_buffer=None, parents_buffer=None, position_ids=None):
+        self.max_width = max_width
+        vocab = draft_model_engine.engine.model.vocab_size
+        gm = {"Successors": [list(range(1, max_width + 1))] + [[] for _ in range(max_width)]}
+        super().__init__(draft_model_engine=draft_model_engine, target_model_engine=target_model_engine, prefix=prefix,
+                         temperature=temperature, top_p=top_p, draft_kv_len=draft_kv_len, target_kv_len=target_kv_len,
+                         max_length=max_length, device=device, max_target_seq=max_length, vocab_size=vocab, grow_map=gm,
+                         attn_mask=attn_mask, sequence=sequence, new_tokens_buffer=new_tokens_buffer,
+                         parents_buffer=parents_buffer, position_ids=position_ids)
+        self.construct_grow_map()
+
+    def verify(self, benchmark=False):
+        from ..native import SQ_RES_LAST_NODE, SQ_RES_N_TREE
+        valid, a, _, terminal = super().verify()
+        res = self.last_result
+        b = int(res[SQ_RES_LAST_NODE]) - 1 if int(res[SQ_RES_N_TREE]) > 0 else -1
+        return valid, a, a, b, terminal

@@ -34,3 +34,34 @@ class SpecTree(NativeTree):
         self.ops.verify_stochastic(self.target_logits, self.draft_logits, self.tokens, self.r, self.gdev["child_off"],
                                    self.gdev["child_ids"], self.tree_size, gt, self.temperature,
                                    self._bonus_uniform(), self.verify_ws, self.result)
+
+
+def _star_growmap(width: int) -> dict:
+    return {"Successors": [list(range(1, width + 1))] + [[] for _ in range(width)]}
+
+
+class SpecTreeTest(SpecTree):
+    """The acceptance-rate probe of tests/test_accept.py (reference: Tree/SpecTree.py:283-489): a one-level tree of
+    `max_width` children, built AND grown by the constructor, rebuilt for every step with the KV lengths carried over;
+    verify(benchmark=True) additionally returns b, the index of the accepted child (-1: none).  Here it is the
+    ordinary SpecTree on a star growmap (same sampler, same verifier kernel — the production rule `p > r q`, where the
+    reference's probe uses `>=`), so the measured vector is the one the production tree will see."""
+
+    def __init__(self, draft_model_engine, target_model_engine, prefix, temperature: float = 0.6, top_p: float = 0.9,
+                 draft_kv_len=0, target_kv_len=0, max_length=256, max_width=32, device="cpu", attn_mask=None,
+                 sequence=None, new_tokens_buffer=None, parents_buffer=None, position_ids=None):
+        self.max_width = max_width
+        vocab = draft_model_engine.engine.model.vocab_size
+        super().__init__(draft_model_engine=draft_model_engine, target_model_engine=target_model_engine, prefix=prefix,
+                         temperature=temperature, top_p=top_p, draft_kv_len=draft_kv_len, target_kv_len=target_kv_len,
+                         max_length=max_length, device=device, max_target_seq=max_length, vocab_size=vocab,
+                         grow_map=_star_growmap(max_width), attn_mask=attn_mask, sequence=sequence,
+                         new_tokens_buffer=new_tokens_buffer, parents_buffer=parents_buffer, position_ids=position_ids)
+        self.construct_grow_map()
+
+    def verify(self, benchmark=False):
+        from ..native import SQ_RES_LAST_NODE, SQ_RES_N_TREE
+        valid, a, _, terminal = super().verify()
+        res = self.last_result
+        b = int(res[SQ_RES_LAST_NODE]) - 1 if int(res[SQ_RES_N_TREE]) > 0 else -1
+        return valid, a, a, b, terminal

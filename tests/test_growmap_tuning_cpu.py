@@ -90,3 +90,39 @@ def test_autoregressive_loop_samples_from_the_target(oracle_ops):
         assert np.abs(full[n0 - 1 + i] - lg[0]).max() < 4e-2
         exp = ops_np.sample_wor(lg.astype(np.float16), rnd.astype(np.float16), 1, meta["T"])
         assert tok == int(exp[0][0])
+
+
+@pytest.mark.parametrize("mode", ["stochastic", "greedy"])
+def test_accept_probe_classes_follow_the_reference_loop(oracle_ops, mode):
+    """tests/test_accept.py's loop: a fresh SpecTreeTest / GreedyTreeTest per step with the KV lengths carried over,
+    verify(benchmark=True) -> (valid_tokens, draft_kv_len, target_kv_len, b, terminate)."""
+    from sequoia_amd.Tree.GreedyTree import GreedyTreeTest
+    from sequoia_amd.Tree.SpecTree import SpecTreeTest
+    draft, target, meta, prompts = _engines()
+    M, w = meta["M"], 5
+    cls = SpecTreeTest if mode == "stochastic" else GreedyTreeTest
+    attn_mask = torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16)
+    position_ids = torch.zeros(M).long()
+    input_ids = torch.tensor(prompts[0][:16]).unsqueeze(0)
+    draft_kv_len = target_kv_len = 0
+    counts = np.zeros(w + 1)
+    torch.manual_seed(2)
+    for step in range(5):
+        tree = cls(prefix=input_ids.squeeze(0), device="cpu", temperature=meta["T"], top_p=1.0, draft_kv_len=draft_kv_len,
+                   target_kv_len=target_kv_len, draft_model_engine=draft, target_model_engine=target, max_length=M,
+                   attn_mask=attn_mask, sequence=None, new_tokens_buffer=None, parents_buffer=None,
+                   position_ids=position_ids, max_width=w)
+        assert tree.Successors[0] == list(range(1, w + 1))
+        valid, draft_kv_len, target_kv_len, b, terminate = tree.verify(benchmark=True)
+        assert -1 <= b < w
+        counts[b] += 1
+        grew = valid.shape[0] - input_ids.shape[1]
+        assert grew == (1 if b < 0 else 2) or terminate
+        assert draft_kv_len == target_kv_len == valid.shape[0] - (0 if terminate else 1)
+        if b >= 0:      # the accepted child is the b-th drawn token
+            assert int(valid[input_ids.shape[1]]) == int(tree.tokens[input_ids.shape[1]])
+        input_ids = valid.clone().unsqueeze(0)
+        if terminate:
+            break
+    assert counts.sum() >= 1
+    draft.clear_kv(); target.clear_kv()
