@@ -33,6 +33,14 @@ def sampling_without_replacement(sampling_logits: torch.Tensor, rand: torch.Tens
     return out
 
 
+def sampling_with_replacement(sampling_logits: torch.Tensor, num_samples: int, temperature: float):
+    """utils.py:20-28.  Despite its name the reference draws WITHOUT replacement here
+    (`multinomial(num_samples, replacement=False)`); so does this: the exponential-race sampler on fresh uniform noise
+    (log(u)/q keys, top-k) is an exact draw without replacement from softmax(logits / T)."""
+    rand = torch.empty_like(sampling_logits).uniform_()
+    return sampling_without_replacement(sampling_logits, rand, num_samples, temperature)
+
+
 def sampling_argmax(sampling_logits: torch.Tensor, num_samples: int):
     """utils.py:29-32 on the native top-k."""
     logits = sampling_logits.reshape(-1, sampling_logits.shape[-1])
@@ -92,4 +100,12 @@ def cuda_graph_for_sampling_argmax(device="cuda:0", dtype=torch.float16, dim=320
                                    mempool=None, idx_len=8, num_samples=16, temperature=0.6, tree_size=64):
     def run(draft_logits):
         return sampling_argmax(draft_logits, num_samples)
+    return _mark_native(run)
+
+
+def cuda_graph_for_sampling_with_replacement(device="cuda:0", dtype=torch.float16, dim=32000, max_length=384, n_warmups=3,
+                                             mempool=None, idx_len=8, num_samples=16, temperature=0.6, tree_size=64):
+    """utils.py:214-248 (used by tests/test_specinfer.py): one callable per tree level, logits -> drawn positions."""
+    def run(draft_logits):
+        return sampling_with_replacement(draft_logits, num_samples, temperature)
     return _mark_native(run)
