@@ -130,23 +130,25 @@ def kernel_rooflines(cfg, loop, device):
     ts = getattr(tgt.model, "ts", None)
     if ts is not None and n <= 128:
         plan = ts.plan(n)
-        for name in ("qkv", "o", "down"):
+        for name in ("qkv", "o", "gate_up", "down"):
             if plan.get(name) is None:
                 continue
             tiles, splits = plan[name]
-            n_out, k, _ = ts.shapes[name]
+            n_out, k, silu = ts.shapes[name]
             xf = ops.repack_rows((torch.randn(n, k, device=device) * 0.5).half())
-            out = torch.empty((n, n_out), dtype=torch.float16, device=device)
+            out = torch.empty(ops.frag_shape(n, n_out) if silu else (n, n_out), dtype=torch.float16, device=device)
             li = [0]
 
-            def proj(name=name, tiles=tiles, splits=splits, n_out=n_out, k=k, xf=xf, out=out):
+            def proj(name=name, tiles=tiles, splits=splits, n_out=n_out, k=k, xf=xf, out=out, silu=silu):
                 w = ts.frag(name, li[0] % L)
                 li[0] += 1
-                ops.linear_ts(xf, w, n, n_out, k, out=out, tiles=tiles, splits=splits, slab=ts._slab if splits > 1 else None)
+                ops.linear_ts(xf, w, n, n_out, k, out=out, silu=silu, out_frag=silu, tiles=tiles, splits=splits,
+                              slab=ts._slab if splits > 1 else None)
             t = timeit(proj, 128, 32)
             out_bytes = splits * n * n_out * 4 if splits > 1 else n * n_out * 2
-            res[f"linear_ts_{name}"] = dict(seconds=t, bytes=n_out * k * 2 + n * k * 2 + out_bytes, launches_per_step=L,
-                                            flops=2 * n * n_out * k, plan=[tiles, splits], pmc_key=f"{name}@{(n + 15) // 16}")
+            w_rows = 2 * n_out if silu else n_out          # SwiGLU: gate rows + up rows
+            res[f"linear_ts_{name}"] = dict(seconds=t, bytes=w_rows * k * 2 + n * k * 2 + out_bytes, launches_per_step=L,
+                                            flops=2 * n * w_rows * k, plan=[tiles, splits], pmc_key=f"{name}@{(n + 15) // 16}")
     return res
 
 

@@ -57,7 +57,7 @@ MAX_SPLITS = 8
 def candidates(n_out: int, k: int, silu: bool, m: int, allow_split: bool = False):
     """(tiles, splits) launch shapes worth timing for one projection."""
     units = n_out // 16
-    max_u = (3 if m <= 64 else 2) if silu else 4
+    max_u = 3 if silu else 4
     ksteps = k // 32
     out = []
     tiles_opts = {(units + u - 1) // u for u in range(1, max_u + 1)}

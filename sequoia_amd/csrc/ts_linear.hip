@@ -43,9 +43,16 @@ struct TsParams {
     int m, mtp, n_out, k, ldo, splits, tiles, units, out_frag;
 };
 
+// row tiles per merge pass: 4 wave images of [16 MH][16 NT + 4] fp32 must fit 150 KB of LDS
+constexpr int ts_merge_tiles(int mt, int nt) {
+    const int per_tile = TS_WAVES * 16 * (nt * 16 + 4) * 4;
+    const int fit = (150 * 1024) / per_tile;
+    return fit >= mt ? mt : fit;
+}
+
 template <int MT, int NT, int D, bool SILU>
 __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P) {
-    extern __shared__ float ts_lds[];                       // 4 waves x [MT*16][LDW] fp32
+    extern __shared__ float ts_lds[];                       // 4 waves x [MH*16][LDW] fp32 (MH = row tiles per merge pass)
     constexpr int LDW = NT * 16 + 4;                         // row stride: 16-byte aligned, 4 rows apart = 16 banks apart
     constexpr int TPU = SILU ? 2 : 1;                        // MFMA column tiles per 16-column output unit
     const int tid = threadIdx.x, lane = tid & 63;
@@ -125,68 +132,73 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
 #undef TS_LOAD
     }
 
-    // ---- the 4 wave partials meet in LDS: image[wave][row][col], MFMA C layout row = 16 mt + 4 g + i -----------
-    float* mine = ts_lds + (size_t)wave * (MT * 16) * LDW;
+    // ---- the 4 wave partials meet in LDS: image[wave][row][col], MFMA C layout row = 16 mt + 4 g + i; MH row tiles per
+    //      pass so that the four images fit the CU's LDS (one pass except for the widest tiles) --------------------
+    constexpr int MH = ts_merge_tiles(MT, NT);
+    const int groups = nu * 2;                                 // output items: (row, 8-column group); a unit holds 2
+    for (int m0 = 0; m0 < MT; m0 += MH) {
+        if (m0 > 0) __syncthreads();                           // the previous pass has been read out
+        float* mine = ts_lds + (size_t)wave * (MH * 16) * LDW;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
+            if (mt >= m0 && mt < m0 + MH)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mine[(mt * 16 + g * 4 + i) * LDW + t * 16 + r16] = acc[mt][t][i];
-    __syncthreads();
-
-    // output items: (row, 8-column group); a unit holds 2 groups
-    const int groups = nu * 2;
-    const int items = P.m * groups;
-    for (int it = tid; it < items; it += TS_THREADS) {
-        const int row = it / groups, grp = it % groups;
-        const int unit = grp >> 1, half = grp & 1;
-        const int col = (unit * TPU) * 16 + half * 8;          // LDS column of the main (gate) values
-        float v[8], u[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { v[j] = 0.f; u[j] = 0.f; }
-#pragma unroll
-        for (int wv = 0; wv < TS_WAVES; ++wv) {
-            const float* src = ts_lds + ((size_t)wv * (MT * 16) + row) * LDW + col;
-            const floatx4 x = *(const floatx4*)src, y = *(const floatx4*)(src + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] += x[j]; v[4 + j] += y[j]; }
-            if (SILU) {
-                const floatx4 p = *(const floatx4*)(src + 16), q = *(const floatx4*)(src + 20);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { u[j] += p[j]; u[4 + j] += q[j]; }
+                    for (int i = 0; i < 4; ++i) mine[((mt - m0) * 16 + g * 4 + i) * LDW + t * 16 + r16] = acc[mt][t][i];
+        __syncthreads();
+        const int row_lo = m0 * 16, row_hi = min(P.m, (m0 + MH) * 16);
+        const int items = max(0, row_hi - row_lo) * groups;
+        for (int it = tid; it < items; it += TS_THREADS) {
+            const int row = row_lo + it / groups, grp = it % groups;
+            const int unit = grp >> 1, half = grp & 1;
+            const int col = (unit * TPU) * 16 + half * 8;          // LDS column of the main (gate) values
+            float v[8], u[8];
+    #pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = 0.f; u[j] = 0.f; }
+    #pragma unroll
+            for (int wv = 0; wv < TS_WAVES; ++wv) {
+                const float* src = ts_lds + ((size_t)wv * (MH * 16) + (row - row_lo)) * LDW + col;
+                const floatx4 x = *(const floatx4*)src, y = *(const floatx4*)(src + 4);
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] += x[j]; v[4 + j] += y[j]; }
+                if (SILU) {
+                    const floatx4 p = *(const floatx4*)(src + 16), q = *(const floatx4*)(src + 20);
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) { u[j] += p[j]; u[4 + j] += q[j]; }
+                }
             }
-        }
-        const int ocol = (u0 + unit) * 16 + half * 8;
-        if (P.splits > 1) {
-            float* dst = P.slab + ((size_t)split * P.m + row) * P.n_out + ocol;
-            *(floatx4*)dst = floatx4{v[0], v[1], v[2], v[3]};
-            *(floatx4*)(dst + 4) = floatx4{v[4], v[5], v[6], v[7]};
-            continue;
-        }
-        half8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            half_t h = (half_t)v[j];
-            if (SILU) {
-                const float gf = (float)h;
-                const half_t sg = (half_t)(gf / (1.0f + expf(-gf)));
-                h = (half_t)((float)sg * (float)(half_t)u[j]);
+            const int ocol = (u0 + unit) * 16 + half * 8;
+            if (P.splits > 1) {
+                float* dst = P.slab + ((size_t)split * P.m + row) * P.n_out + ocol;
+                *(floatx4*)dst = floatx4{v[0], v[1], v[2], v[3]};
+                *(floatx4*)(dst + 4) = floatx4{v[4], v[5], v[6], v[7]};
+                continue;
             }
-            o[j] = h;
+            half8 o;
+    #pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                half_t h = (half_t)v[j];
+                if (SILU) {
+                    const float gf = (float)h;
+                    const half_t sg = (half_t)(gf / (1.0f + expf(-gf)));
+                    h = (half_t)((float)sg * (float)(half_t)u[j]);
+                }
+                o[j] = h;
+            }
+            if (P.out_frag) {      // element (row, ocol + j) -> [ocol / 32][row / 16][(ocol / 8 % 4) * 16 + row % 16][j]
+                const size_t foff = (((size_t)(ocol >> 5) * P.mtp + (row >> 4)) * 64 + ((ocol >> 3) & 3) * 16 + (row & 15)) * 8;
+                *(half8*)(P.out + foff) = o;
+                continue;
+            }
+            const size_t off = (size_t)row * P.ldo + ocol;
+            if (!SILU && P.res) {
+                const half8 r = *(const half8*)(P.res + off);
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)o[j] + (float)r[j]);
+            }
+            *(half8*)(P.out + off) = o;
         }
-        if (P.out_frag) {      // element (row, ocol + j) -> [ocol / 32][row / 16][(ocol / 8 % 4) * 16 + row % 16][j]
-            const size_t foff = (((size_t)(ocol >> 5) * P.mtp + (row >> 4)) * 64 + ((ocol >> 3) & 3) * 16 + (row & 15)) * 8;
-            *(half8*)(P.out + foff) = o;
-            continue;
-        }
-        const size_t off = (size_t)row * P.ldo + ocol;
-        if (!SILU && P.res) {
-            const half8 r = *(const half8*)(P.res + off);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)o[j] + (float)r[j]);
-        }
-        *(half8*)(P.out + off) = o;
     }
 }
 
@@ -202,7 +214,7 @@ static void ts_go(const TsParams& P, hipStream_t st) {
     // faster -- the stream is bound by the CU's memory ingest (~14 B/clk/CU for weights + activations together),
     // not by bytes in flight or by the VGPR return path.
     constexpr int D = (MT * NT > 24) ? 3 : 4;
-    const size_t lds = (size_t)TS_WAVES * MT * 16 * (NT * 16 + 4) * sizeof(float);
+    const size_t lds = (size_t)TS_WAVES * ts_merge_tiles(MT, NT) * 16 * (NT * 16 + 4) * sizeof(float);
     auto kern = ts_linear_kernel<MT, NT, D, SILU>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
@@ -214,7 +226,7 @@ static int ts_dispatch(const TsParams& P, int silu, int nt, hipStream_t st) {
     if (silu) {
         if (nt <= 2) ts_go<MT, 2, true>(P, st);
         else if (nt <= 4) ts_go<MT, 4, true>(P, st);
-        else if (nt <= 6 && MT <= 4) ts_go<MT, (MT <= 4 ? 6 : 4), true>(P, st);
+        else if (nt <= 6) ts_go<MT, 6, true>(P, st);
         else return SQ_EUNSUPPORTED;
         return SQ_OK;
     }

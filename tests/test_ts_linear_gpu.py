@@ -73,7 +73,8 @@ def test_linear_ts_bit_exact_on_order_independent_operands(m, n, k, tiles, split
 
 
 @pytest.mark.parametrize("m,inter,k,tiles,out_frag", [(16, 64, 128, 2, False), (34, 3072, 768, 96, True), (48, 11008, 4096, 230, True),
-                                                      (64, 1024, 512, 32, False), (128, 2048, 1024, 64, True), (100, 5504, 256, 172, True)])
+                                                      (64, 1024, 512, 32, False), (128, 2048, 1024, 64, True), (100, 5504, 256, 172, True),
+                                                      (128, 11008, 512, 230, True), (96, 3072, 768, 64, False)])
 def test_linear_ts_swiglu_epilogue(m, inter, k, tiles, out_frag):
     ops = _ops()
     rng = np.random.default_rng(inter + m)
@@ -238,7 +239,7 @@ def test_plan_candidates_respect_kernel_limits():
         units = n_out // 16
         for tiles, splits in candidates(n_out, k, silu, m, allow_split=not silu):
             per = (units + tiles - 1) // tiles
-            assert per <= ((3 if m <= 64 else 2) if silu else 4)
+            assert per <= (3 if silu else 4)
             assert k // 32 >= splits * 8 and (splits == 1 or not silu)
 
 

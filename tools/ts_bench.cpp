@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(dr, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
             // (tiles, splits) candidates
             std::vector<std::pair<int, int>> cands;
-            const int max_u = sh.silu ? (m <= 64 ? 3 : 2) : 4;
+            const int max_u = sh.silu ? 3 : 4;
             for (int upt = 1; upt <= max_u; ++upt)
                 for (int sp : {1, 2, 3, 4, 6, 8}) {
                     const int tiles = (units + upt - 1) / upt;
