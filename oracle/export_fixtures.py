@@ -9,7 +9,6 @@ pre-tokenised dataset/c4_small.json (Llama-2 vocabulary ids), first 128 tokens e
 import hashlib
 import json
 import os
-import sys
 
 import torch
 

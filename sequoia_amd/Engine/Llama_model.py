@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from ..ops import get_ops
-from .Llama_modules import LayerWeights, TreeContext, attention_block, attention_core, mlp_block, rope_tables
+from .Llama_modules import LayerWeights, TreeContext, attention_block, mlp_block, rope_tables
 from .ts_linear import MAX_ROWS as TS_MAX_ROWS
 from .ts_linear import TsLinearSet, forward_ts
 

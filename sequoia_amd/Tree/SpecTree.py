@@ -4,8 +4,6 @@ native kernels.  Same constructor and step API; the per-child host loop of the r
 """
 from __future__ import annotations
 
-import torch
-
 from ._native_tree import NativeTree
 
 

@@ -17,7 +17,7 @@ import time
 import torch
 
 from ..Engine.Llama_modules import TreeContext
-from ..native import (SQ_VERIFY_GATHER_FIRST, SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_SLOTS, SQ_RES_TERMINAL, SQ_RESULT_INTS)
+from ..native import (SQ_VERIFY_GATHER_FIRST, SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_TERMINAL, SQ_RESULT_INTS)
 from ..ops import get_ops
 from .Tree import Tree, growmap_on_device
 

@@ -1,5 +1,4 @@
 """CPU checks of the C-ABI boundary and the drop-in aliases (no GPU, no compute launches)."""
-import ctypes
 import os
 import re
 import sys

@@ -1,6 +1,5 @@
 """API-level behaviour on the GPU: KV_Cache methods, engine helpers, terminal conditions, hipGraph
 capturability of every device entry point of the C ABI."""
-import numpy as np
 import pytest
 import torch
 

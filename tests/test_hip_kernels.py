@@ -64,7 +64,6 @@ def test_tree_mask_dense(ops, n, gt):
     bm = O.bitmask_from_successors(succ)
     off, ids = csr(succ)
     # host helper of the library agrees with the oracle bit for bit
-    import ctypes
     out = np.zeros_like(bm)
     rc = ops.lib.sq_tree_bitmask_from_successors(off.ctypes.data, ids.ctypes.data if len(ids) else None, n,
                                                  out.ctypes.data, bm.shape[1])

@@ -1,6 +1,6 @@
 """Probe: how fast does PyTorch-ROCm (hipBLASLt / rocBLAS) run the 7B verify projections at M=128?
 Prints us and effective weight-streaming TB/s per shape and call form."""
-import os, sys, time
+import os, sys
 import torch
 import torch.nn.functional as F
 

@@ -5,7 +5,6 @@ M=384).  Measurement tooling only.
 
     python tools/torch_ops_baseline.py
 """
-import json
 import math
 import os
 import sys
