@@ -146,6 +146,13 @@ int sq_rope_tree_attention_f16(const void* qkv, int qkv_stride, void* k_layer, v
  * update a d_ctx block between graph replays without a host->device copy.                    */
 int sq_store_i32(int32_t* dst, int n, int v0, int v1, int v2, int v3, void* stream);
 
+/* One launch that stages a captured forward's inputs: the q_len new tokens' input_ids / position_ids / storage_ids are
+ * copied into the graph's static buffers and (d_ctx != NULL) its {q_slot0, gt, kv_len} block is written -- the four
+ * copy_ calls of the reference's capture_graph closure (Engine/Engine.py:156-163).  All arrays int64, contiguous. */
+int sq_stage_inputs(int64_t* dst_ids, const int64_t* src_ids, int64_t* dst_pos, const int64_t* src_pos,
+                    int64_t* dst_storage, const int64_t* src_storage, int q_len, int32_t* d_ctx, int q_slot0, int gt,
+                    int kv_len, void* stream);
+
 /* ---- a2: draft expansion samplers ------------------------------------------------------- */
 /* utils.sampling_without_replacement (utils.py:10-18) for n_rows rows:
  * q = softmax(logits/T) (fp16), key = log(u)/q (fp16), take the k largest keys per row in

@@ -119,14 +119,25 @@ class _GraphRunner:
 
     def replay(self, input_ids, storage_ids, position_ids, attn_mask=None, tree: TreeContext | None = None,
                borrow: bool = False):
-        self.input_ids.copy_(input_ids)
-        self.storage_ids.copy_(storage_ids)
-        self.position_ids.copy_(position_ids)
         kv = self.engine.kv_cache
-        if self.mode == "dense":
-            self.mask.copy_(attn_mask)
+        ops = get_ops()
+        fast = (hasattr(ops, "stage_inputs") and input_ids.is_contiguous() and storage_ids.is_contiguous()
+                and position_ids.is_contiguous() and input_ids.dtype == storage_ids.dtype == position_ids.dtype == torch.int64)
+        if fast:                             # one launch instead of three copies (+ the context store)
+            if self.mode == "dense":
+                ops.stage_inputs(self.input_ids, input_ids, self.position_ids, position_ids, self.storage_ids, storage_ids)
+                self.mask.copy_(attn_mask)
+            else:
+                ops.stage_inputs(self.input_ids, input_ids, self.position_ids, position_ids, self.storage_ids, storage_ids,
+                                 ctx=self.ctx, q_slot0=tree.q_slot0, gt=tree.gt, kv_len=tree.kv_len)
         else:
-            get_ops().store_i32(self.ctx, [tree.q_slot0, tree.gt, tree.kv_len])
+            self.input_ids.copy_(input_ids)
+            self.storage_ids.copy_(storage_ids)
+            self.position_ids.copy_(position_ids)
+            if self.mode == "dense":
+                self.mask.copy_(attn_mask)
+            else:
+                ops.store_i32(self.ctx, [tree.q_slot0, tree.gt, tree.kv_len])
         self.graph.replay()
         kv.note_written(self.q_len)          # host-side bookkeeping the captured forward cannot replay
         # `borrow`: the caller consumes the static output before the next replay (stream order), no clone

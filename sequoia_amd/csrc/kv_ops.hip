@@ -31,6 +31,30 @@ extern "C" int sq_store_i32(int32_t* dst, int n, int v0, int v1, int v2, int v3,
     return sq_check_launch();
 }
 
+// Stages the inputs of a captured forward in one launch: input_ids / position_ids / storage_ids of the q_len new tokens are
+// copied from the tree's buffers into the graph's static buffers, and the {q_slot0, gt, kv_len} context block is written
+// (what the reference's capture_graph closure does with four copy_ calls, Engine/Engine.py:156-163).
+__global__ void stage_inputs_kernel(int64_t* __restrict__ dst_ids, const int64_t* __restrict__ src_ids,
+                                    int64_t* __restrict__ dst_pos, const int64_t* __restrict__ src_pos,
+                                    int64_t* __restrict__ dst_sto, const int64_t* __restrict__ src_sto, int q_len,
+                                    int32_t* __restrict__ ctx, int c0, int c1, int c2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < q_len) {
+        dst_ids[i] = src_ids[i];
+        dst_pos[i] = src_pos[i];
+        dst_sto[i] = src_sto[i];
+    }
+    if (ctx && i < 3) ctx[i] = i == 0 ? c0 : (i == 1 ? c1 : c2);
+}
+extern "C" int sq_stage_inputs(int64_t* dst_ids, const int64_t* src_ids, int64_t* dst_pos, const int64_t* src_pos,
+                               int64_t* dst_storage, const int64_t* src_storage, int q_len, int32_t* d_ctx, int q_slot0,
+                               int gt, int kv_len, void* stream) {
+    if (!dst_ids || !src_ids || !dst_pos || !src_pos || !dst_storage || !src_storage || q_len <= 0) return SQ_EINVAL;
+    hipLaunchKernelGGL(stage_inputs_kernel, dim3((q_len + 127) / 128), dim3(128), 0, (hipStream_t)stream, dst_ids, src_ids,
+                       dst_pos, src_pos, dst_storage, src_storage, q_len, d_ctx, q_slot0, gt, kv_len);
+    return sq_check_launch();
+}
+
 // ---- a1: bitmask from children CSR (host) ----------------------------------------------------
 extern "C" int sq_tree_bitmask_from_successors(const int32_t* child_off, const int32_t* child_ids,
                                                int n, uint64_t* out, int words) {

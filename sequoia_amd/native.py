@@ -40,6 +40,7 @@ PROTOTYPES = {
     "sq_store_i32": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "sq_sample_wor_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "sq_topk_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sq_stage_inputs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sq_verify_workspace_bytes": (C.c_size_t, [_i]),
     "sq_sample_iid_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "sq_verify_specinfer_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp]),

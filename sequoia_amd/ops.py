@@ -103,6 +103,17 @@ class HipOps:
         check(self.lib.sq_store_i32(dst.data_ptr(), len(values), int(v[0]), int(v[1]), int(v[2]), int(v[3]),
                                     self._stream()), "sq_store_i32")
 
+    def stage_inputs(self, dst_ids, src_ids, dst_pos, src_pos, dst_storage, src_storage, ctx=None, q_slot0=0, gt=1, kv_len=1):
+        """Copy a forward's new-token inputs into a graph's static buffers and write its context block, one launch."""
+        q_len = src_ids.numel()
+        for t, n in ((dst_ids, "dst_ids"), (src_ids, "src_ids"), (dst_pos, "dst_pos"), (src_pos, "src_pos"),
+                     (dst_storage, "dst_storage"), (src_storage, "src_storage")):
+            _need(t, torch.int64, n)
+            assert t.numel() == q_len
+        check(self.lib.sq_stage_inputs(dst_ids.data_ptr(), src_ids.data_ptr(), dst_pos.data_ptr(), src_pos.data_ptr(),
+                                       dst_storage.data_ptr(), src_storage.data_ptr(), q_len, _ptr(ctx), int(q_slot0),
+                                       int(gt), int(kv_len), self._stream()), "sq_stage_inputs")
+
     def tree_attention(self, q, k_layer, v_layer, out, kv_len, scale, dense_mask=None, q_slot0=0, gt=0, n_tree=0,
                        bitmask=None, ctx=None, out_frag=False):
         """q: [H, q_len, D]; k/v_layer: [H_kv, M, D]; out: [q_len, H*D], or (out_frag) its fragment-major image
