@@ -98,46 +98,56 @@ extern "C" int sq_add_rmsnorm_frag_f16(const void* x, const void* residual, void
 // Same as rmsnorm_kernel<true>, with x arriving as `splits` fp32 partial products of a split-K linear layer
 // (sq_linear_ts_f16): x = h(((s0 + s1) + s2) + ...) -- the layer's fp16 output rounding -- then h = x + res.
 // NORM = false stops after the add (the sum feeds a later, separate normalisation).
-template <bool NORM>
-__global__ void __launch_bounds__(ROW_THREADS)
+// One pass: a thread owns CPT 8-element chunks of the row (THREADS x CPT >= hidden / 8), every load of the row -- the
+// slabs, the residual, the norm weight -- is issued before the first use, the summed row stays in registers across the
+// block reduction, so the kernel is one memory latency + one reduction deep (64 launches per 7B verify).
+template <int THREADS, int CPT, bool NORM>
+__global__ void __launch_bounds__(THREADS)
 rmsnorm_slabs_kernel(const float* __restrict__ slab, int splits, size_t split_stride, const half_t* __restrict__ res,
                      half_t* __restrict__ sum_out, const half_t* __restrict__ w, half_t* __restrict__ out, int hidden,
                      float eps, int frag_mtp) {
-    __shared__ float s_f[ROW_WAVES];
+    __shared__ float s_f[THREADS / 64];
     const size_t row = blockIdx.x;
     const int chunks = hidden >> 3;
+    half8 v[CPT], wv[CPT];
     float ss = 0.f;
-    for (int c = threadIdx.x; c < chunks; c += ROW_THREADS) {
-        const float* sp = slab + row * hidden + c * 8;
-        floatx4 a = *(const floatx4*)sp, b = *(const floatx4*)(sp + 4);
-        for (int s = 1; s < splits; ++s) {
-            a += *(const floatx4*)(sp + s * split_stride);
-            b += *(const floatx4*)(sp + s * split_stride + 4);
-        }
-        const half8 r = *(const half8*)(res + row * hidden + c * 8);
-        half8 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = (half_t)((float)(half_t)a[j] + (float)r[j]);
-            v[4 + j] = (half_t)((float)(half_t)b[j] + (float)r[4 + j]);
-        }
-        *(half8*)(sum_out + row * hidden + c * 8) = v;
+    for (int i = 0; i < CPT; ++i) {
+        const int c = threadIdx.x + i * THREADS;
+        if (c < chunks) {
+            const float* sp = slab + row * hidden + c * 8;
+            floatx4 a = *(const floatx4*)sp, b = *(const floatx4*)(sp + 4);
+            for (int s = 1; s < splits; ++s) {
+                a += *(const floatx4*)(sp + s * split_stride);
+                b += *(const floatx4*)(sp + s * split_stride + 4);
+            }
+            const half8 r = *(const half8*)(res + row * hidden + c * 8);
+            if (NORM) wv[i] = *(const half8*)(w + c * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+            for (int j = 0; j < 4; ++j) {
+                v[i][j] = (half_t)((float)(half_t)a[j] + (float)r[j]);
+                v[i][4 + j] = (half_t)((float)(half_t)b[j] + (float)r[4 + j]);
+            }
+            *(half8*)(sum_out + row * hidden + c * 8) = v[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += (float)v[i][j] * (float)v[i][j];
+        }
     }
     if (!NORM) return;
-    const float tot = block_sum_f32<ROW_WAVES>(ss, s_f);
+    const float tot = block_sum_f32<THREADS / 64>(ss, s_f);
     const float inv = rsqrtf(tot / (float)hidden + eps);
-    for (int c = threadIdx.x; c < chunks; c += ROW_THREADS) {
-        const half8 v = *(const half8*)(sum_out + row * hidden + c * 8);      // this thread's own stores above
-        const half8 wv = *(const half8*)(w + c * 8);
-        half8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const half_t n = (half_t)((float)v[j] * inv);
-            o[j] = (half_t)((float)wv[j] * (float)n);
+    for (int i = 0; i < CPT; ++i) {
+        const int c = threadIdx.x + i * THREADS;
+        if (c < chunks) {
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const half_t n = (half_t)((float)v[i][j] * inv);
+                o[j] = (half_t)((float)wv[i][j] * (float)n);
+            }
+            *(half8*)(out + (frag_mtp ? frag_chunk_offset(row, c, frag_mtp) : row * hidden + c * 8)) = o;
         }
-        *(half8*)(out + (frag_mtp ? frag_chunk_offset(row, c, frag_mtp) : row * hidden + c * 8)) = o;
     }
 }
 
@@ -145,17 +155,29 @@ extern "C" int sq_add_rmsnorm_slabs_f16(const void* slab, int splits, const void
                                          void* sum_out, void* out, int out_frag, int rows, int hidden, float eps,
                                          void* stream) {
     if (!slab || !residual || !sum_out || splits < 1 || rows < 0 || hidden <= 0 || (out && !weight)) return SQ_EINVAL;
-    if ((hidden & 7) || ((uintptr_t)slab & 15) || (out_frag && (hidden & 31))) return SQ_EUNSUPPORTED;
+    if ((hidden & 7) || ((uintptr_t)slab & 15) || (out_frag && (hidden & 31)) || hidden > 8 * 1024 * 4) return SQ_EUNSUPPORTED;
     if (rows == 0) return SQ_OK;
     const size_t stride = (size_t)rows * hidden;
-    if (out)
-        hipLaunchKernelGGL((rmsnorm_slabs_kernel<true>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                           (const float*)slab, splits, stride, (const half_t*)residual, (half_t*)sum_out,
-                           (const half_t*)weight, (half_t*)out, hidden, eps, out_frag ? (rows + 15) / 16 : 0);
-    else
-        hipLaunchKernelGGL((rmsnorm_slabs_kernel<false>), dim3(rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                           (const float*)slab, splits, stride, (const half_t*)residual, (half_t*)sum_out,
-                           (const half_t*)nullptr, (half_t*)nullptr, hidden, eps, 0);
+    const int chunks = hidden >> 3;
+    const int mtp = out_frag ? (rows + 15) / 16 : 0;
+    hipStream_t st = (hipStream_t)stream;
+#define SQ_SLABS(T_, C_)                                                                                           \
+    {                                                                                                              \
+        if (out)                                                                                                   \
+            hipLaunchKernelGGL((rmsnorm_slabs_kernel<T_, C_, true>), dim3(rows), dim3(T_), 0, st, (const float*)slab,  \
+                               splits, stride, (const half_t*)residual, (half_t*)sum_out, (const half_t*)weight,       \
+                               (half_t*)out, hidden, eps, mtp);                                                        \
+        else                                                                                                       \
+            hipLaunchKernelGGL((rmsnorm_slabs_kernel<T_, C_, false>), dim3(rows), dim3(T_), 0, st, (const float*)slab, \
+                               splits, stride, (const half_t*)residual, (half_t*)sum_out, (const half_t*)nullptr,      \
+                               (half_t*)nullptr, hidden, eps, 0);                                                      \
+    }
+    if (chunks <= 256) SQ_SLABS(256, 1)
+    else if (chunks <= 512) SQ_SLABS(512, 1)
+    else if (chunks <= 1024) SQ_SLABS(1024, 1)
+    else if (chunks <= 2048) SQ_SLABS(1024, 2)
+    else SQ_SLABS(1024, 4)
+#undef SQ_SLABS
     return sq_check_launch();
 }
 
