@@ -290,6 +290,12 @@ size_t sq_linear_ts_workspace_bytes(int m, int n_out, int splits);
 int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const void* res, void* out, int ldo, int out_frag, int m,
                      int n_out, int k, int silu, int tiles, int splits, void* slab, size_t slab_bytes, void* stream);
 
+/* Embedding lookup + the first RMSNorm of a forward in one pass (Engine/Llama_model.py:151 + the first layer's
+ * input_layernorm, Engine/Llama_modules.py:282-288): x_out[r] = embed[ids[r]] (the residual stream, row-major),
+ * out = RMSNorm(x_out) * weight, row-major or (out_frag) fragment-major.  ids: int64 [rows], clamped to [0, vocab).   */
+int sq_embed_rmsnorm_f16(const int64_t* d_ids, const void* embed, int vocab, const void* weight, void* x_out, void* out,
+                         int out_frag, int rows, int hidden, float eps, void* stream);
+
 /* Residual add + RMSNorm fed by a split-K linear layer: x = h(sum_s slab[s]) (the layer's fp16 output),
  * then exactly sq_add_rmsnorm_f16: sum_out = x + residual (fp16), out = RMSNorm(sum_out) * weight
  * (Engine/Llama_modules.py:282-288,341-346).  out == NULL skips the normalisation (last layer's skip add

@@ -305,10 +305,10 @@ class _LlamaForCausalLM:
                                      f"{tuple(attention_mask.size())}")
             if dense.dtype != self.dtype:
                 dense = dense.to(self.dtype)
-        x = F.embedding(input_ids[0], W.embed)                      # [q, hidden]
         # (reduce_fn / gather_logits_fn are attached after construction by the TP engine: check at call time)
         if (self.ts is not None and q_len <= TS_MAX_ROWS and self.reduce_fn is None and self.gather_logits_fn is None):
-            return forward_ts(self, self.ts, x, q_len, pos, storage_ids, dense, tree, kv_cache)
+            return forward_ts(self, self.ts, input_ids[0], q_len, pos, storage_ids, dense, tree, kv_cache)
+        x = F.embedding(input_ids[0], W.embed)                      # [q, hidden]
         hbuf = torch.empty_like(x)
         pending = None                                               # branch output not yet added to x
         for li, lw in enumerate(W.layers):

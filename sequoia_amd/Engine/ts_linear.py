@@ -220,16 +220,18 @@ class TsLinearSet:
         return best
 
 
-def forward_ts(model, ts: TsLinearSet, x, q_len, pos, storage_ids, dense, tree, kv_cache):
-    """Decoder forward of <= 128 tree tokens on the tall-skinny projections.  x: [q, hidden] embeddings.
+def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree, kv_cache):
+    """Decoder forward of <= 128 tree tokens on the tall-skinny projections.  ids: int64 [q] token ids.
     Returns logits [1, q, V]."""
     from .Llama_modules import attention_core
     ops = get_ops()
     W, dims = model.weights, model.dims
     eps = dims.rms_norm_eps
     plan = ts.plan(q_len)
-    dev, dt = x.device, x.dtype
+    dev, dt = W.embed.device, W.embed.dtype
     hidden = dims.hidden_size
+    ids = ids.contiguous()
+    x = torch.empty((q_len, hidden), dtype=dt, device=dev)           # the residual stream
     inter = ts.shapes["down"][1]
     vocab = ts.shapes["lm_head"][0]
     fs = ops.frag_shape
@@ -266,7 +268,12 @@ def forward_ts(model, ts: TsLinearSet, x, q_len, pos, storage_ids, dense, tree, 
 
     pending = None
     for li, lw in enumerate(W.layers):
-        h = norm_into(pending, lw.ln1, plan["qkv"] is not None)
+        if li == 0:                                              # embedding lookup + first norm, one launch
+            want = plan["qkv"] is not None
+            h = torch.empty(fs(q_len, hidden) if want else (q_len, hidden), dtype=dt, device=dev)
+            ops.embed_rmsnorm(ids, W.embed, lw.ln1, x, h, eps, out_frag=want)
+        else:
+            h = norm_into(pending, lw.ln1, plan["qkv"] is not None)
         qkv = project("qkv", li, h)[1]
         attn = attention_core(qkv, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
                               out_frag=plan["o"] is not None)

@@ -95,6 +95,70 @@ extern "C" int sq_add_rmsnorm_frag_f16(const void* x, const void* residual, void
     return sq_check_launch();
 }
 
+// First norm of a forward fused with the embedding lookup (Engine/Llama_model.py:151 `embed_tokens(input_ids)` +
+// the first decoder layer's input_layernorm): row r of the residual stream is embed[ids[r]]; it is written out (the
+// residual stream) and normalised in the same pass, row-major or fragment-major.  Same arithmetic as rmsnorm_kernel.
+template <int THREADS, int CPT>
+__global__ void __launch_bounds__(THREADS)
+embed_rmsnorm_kernel(const int64_t* __restrict__ ids, const half_t* __restrict__ embed, int vocab,
+                     const half_t* __restrict__ w, half_t* __restrict__ x_out, half_t* __restrict__ out, int hidden,
+                     float eps, int frag_mtp) {
+    __shared__ float s_f[THREADS / 64];
+    const size_t row = blockIdx.x;
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const half_t* src = embed + (size_t)id * hidden;
+    const int chunks = hidden >> 3;
+    half8 v[CPT], wv[CPT];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = threadIdx.x + i * THREADS;
+        if (c < chunks) {
+            v[i] = *(const half8*)(src + c * 8);
+            wv[i] = *(const half8*)(w + c * 8);
+            *(half8*)(x_out + row * hidden + c * 8) = v[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += (float)v[i][j] * (float)v[i][j];
+        }
+    }
+    const float tot = block_sum_f32<THREADS / 64>(ss, s_f);
+    const float inv = rsqrtf(tot / (float)hidden + eps);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = threadIdx.x + i * THREADS;
+        if (c < chunks) {
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const half_t n = (half_t)((float)v[i][j] * inv);
+                o[j] = (half_t)((float)wv[i][j] * (float)n);
+            }
+            *(half8*)(out + (frag_mtp ? frag_chunk_offset(row, c, frag_mtp) : row * hidden + c * 8)) = o;
+        }
+    }
+}
+
+extern "C" int sq_embed_rmsnorm_f16(const int64_t* d_ids, const void* embed, int vocab, const void* weight, void* x_out,
+                                    void* out, int out_frag, int rows, int hidden, float eps, void* stream) {
+    if (!d_ids || !embed || !weight || !x_out || !out || rows < 0 || hidden <= 0 || vocab <= 0) return SQ_EINVAL;
+    if ((hidden & 7) || (out_frag && (hidden & 31)) || hidden > 8 * 1024 * 4) return SQ_EUNSUPPORTED;
+    if (rows == 0) return SQ_OK;
+    const int chunks = hidden >> 3;
+    const int mtp = out_frag ? (rows + 15) / 16 : 0;
+    hipStream_t st = (hipStream_t)stream;
+#define SQ_EMB(T_, C_)                                                                                             \
+    hipLaunchKernelGGL((embed_rmsnorm_kernel<T_, C_>), dim3(rows), dim3(T_), 0, st, d_ids, (const half_t*)embed, vocab,   \
+                       (const half_t*)weight, (half_t*)x_out, (half_t*)out, hidden, eps, mtp)
+    if (chunks <= 256) SQ_EMB(256, 1);
+    else if (chunks <= 512) SQ_EMB(512, 1);
+    else if (chunks <= 1024) SQ_EMB(1024, 1);
+    else if (chunks <= 2048) SQ_EMB(1024, 2);
+    else SQ_EMB(1024, 4);
+#undef SQ_EMB
+    return sq_check_launch();
+}
+
 // Same as rmsnorm_kernel<true>, with x arriving as `splits` fp32 partial products of a split-K linear layer
 // (sq_linear_ts_f16): x = h(((s0 + s1) + s2) + ...) -- the layer's fp16 output rounding -- then h = x + res.
 // NORM = false stops after the add (the sum feeds a later, separate normalisation).

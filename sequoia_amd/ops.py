@@ -337,6 +337,17 @@ class HipOps:
                                                 float(eps), self._stream()), "sq_add_rmsnorm_slabs_f16")
         return out
 
+    def embed_rmsnorm(self, ids, embed, weight, x_out, out, eps, out_frag=False):
+        """x_out = embed[ids]; out = RMSNorm(x_out) * weight (row-major or fragment-major), one launch."""
+        _need(ids, torch.int64, "ids"); _need(embed, torch.float16, "embed"); _need(weight, torch.float16, "weight")
+        _need(x_out, torch.float16, "x_out"); _need(out, torch.float16, "out")
+        rows, hidden = x_out.shape
+        assert ids.numel() == rows and embed.shape[1] == hidden
+        check(self.lib.sq_embed_rmsnorm_f16(ids.data_ptr(), embed.data_ptr(), embed.shape[0], weight.data_ptr(),
+                                            x_out.data_ptr(), out.data_ptr(), 1 if out_frag else 0, rows, hidden,
+                                            float(eps), self._stream()), "sq_embed_rmsnorm_f16")
+        return out
+
     def rmsnorm_frag(self, x, weight, out_frag, eps):
         _need(x, torch.float16, "x"); _need(weight, torch.float16, "weight"); _need(out_frag, torch.float16, "out_frag")
         hidden = x.shape[-1]

@@ -268,3 +268,24 @@ def test_tensor_parallel_hooks_disable_the_tall_skinny_path(monkeypatch):
     eng.inference(input_ids=ids, storage_ids=ar, position_ids=ar[None], attn_mask=None,
                   tree=TreeContext(q_slot0=0, gt=20, n_tree=1, bitmask=bm, kv_len=20, contiguous_slots=True))
     assert len(calls) == 4          # o_proj and down_proj of both layers went through the hook
+
+
+@pytest.mark.parametrize("rows,hidden,vocab,frag", [(1, 768, 1000, True), (34, 768, 32000, False), (128, 4096, 32000, True), (48, 5120, 500, True)])
+def test_embed_rmsnorm_equals_gather_then_rmsnorm(rows, hidden, vocab, frag):
+    ops = _ops()
+    torch.manual_seed(rows + hidden)
+    embed = torch.randn(vocab, hidden, device=DEV).half()
+    wt = (1 + 0.1 * torch.randn(hidden, device=DEV)).half()
+    ids = torch.randint(0, vocab, (rows,), device=DEV)
+    x = torch.empty((rows, hidden), dtype=torch.float16, device=DEV)
+    out = torch.zeros(ops.frag_shape(rows, hidden) if frag else (rows, hidden), dtype=torch.float16, device=DEV)
+    ops.embed_rmsnorm(ids, embed, wt, x, out, 1e-6, out_frag=frag)
+    x_ref = embed[ids]
+    assert torch.equal(x, x_ref)
+    ref = torch.empty_like(x_ref)
+    ops.rmsnorm(x_ref.contiguous(), wt, ref, 1e-6)
+    got = out.cpu().numpy()
+    got = O.unfrag_rows(got, rows, hidden) if frag else got
+    d = np.abs(got.astype(np.float32) - ref.cpu().numpy().astype(np.float32))
+    # the row statistic is reduced over another thread count: last-bit differences on a few elements at most
+    assert (d > 0).mean() < 5e-3 and d.max() <= np.abs(ref.float().cpu().numpy()).max() * 2 ** -9
