@@ -11,8 +11,10 @@ construct_grow_map() + verify().
     python bench.py --gpus N --steps K --warmup W
 
 N > 1 = independent replicas (one process per GPU, prompts sharded rank::world, no data-path
-collective: the loop is a batch-1 latency loop).
-Prints one JSON line (rank 0).
+collective: the loop is a batch-1 latency loop); `--config E` shards the 70B
+target tensor-parallel over the N ranks instead (RCCL all-reduce over xGMI).  When N > 1 and the
+process was not started by torchrun (no WORLD_SIZE in the environment) bench.py launches the N
+ranks itself through torch.distributed.run on 127.0.0.1.  Prints one JSON line (rank 0).
 """
 from __future__ import annotations
 
@@ -196,6 +198,47 @@ def cpu_baseline(cfg, n_steps=1, pair="calibrated"):
         ops_mod.set_ops_for_testing(prev)
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks (one process per GPU) and relay their output;
+    rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def selftest(args, world, rank):
+    """Launcher / rendezvous / aggregation check without a model: K timed no-op steps per rank, the same barrier +
+    max-over-ranks timing and the same JSON assembly as the real run (used by the CPU test of the N > 1 path)."""
+    import torch.distributed as dist
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    secs = time.perf_counter() - t0
+    ranks = 1
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([secs]); dist.all_reduce(t, op=dist.ReduceOp.MAX); secs = float(t)
+        c = torch.tensor([float(args.steps)]); dist.all_reduce(c); steps_all = float(c)
+        ranks = dist.get_world_size()
+    else:
+        steps_all = float(args.steps)
+    if rank == 0:
+        print(json.dumps(dict(metric="accepted tokens/sec", value=None, unit="tokens/s", n_gpus=world, steps=args.steps,
+                              warmup=args.warmup, ms_per_step=secs / args.steps * 1e3, higher_is_better=True,
+                              scaling="weak", vs_baseline=None, dtype="f16", data="synthetic", selftest=True,
+                              rccl_ranks=ranks, steps_per_s=steps_all / secs,
+                              config=dict(workload="launcher selftest (no model)", parallelism="replicas" if world > 1 else "single"))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,15 +254,26 @@ def main():
     ap.add_argument("--no-autoregressive", action="store_true", help="skip the target-only baseline (simulation_baseline)")
     ap.add_argument("--no-tuned-growmap", action="store_true",
                     help="skip the second timed loop on the growmap searched for this GPU (config B only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--selftest", action="store_true", help="launcher / aggregation check without a model (CPU-runnable)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group("gloo")
+    if args.selftest:
+        return selftest(args, world, rank)
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
     torch.manual_seed(17 + rank)
@@ -244,9 +298,11 @@ def main():
     torch.cuda.synchronize()
     secs, new_tok, steps = loop.run_steps(args.steps)
     torch.cuda.synchronize()
+    rccl_ranks = 1
     if world > 1:
         dist.barrier()
         t = torch.tensor([secs], device=device); dist.all_reduce(t, op=dist.ReduceOp.MAX); secs = float(t)
+        rccl_ranks = dist.get_world_size()
         if tp_mode:                    # all ranks produced the SAME tokens: count them once
             steps_all = steps
         else:
@@ -322,7 +378,7 @@ def main():
                                 parallelism=(f"tp{world}" if tp_mode else ("replicas" if world > 1 else "single")), graphs=not args.no_graphs,
                                 gemm="torch TunableOp (hipBLASLt/rocBLAS solution picked per shape)" if gemm_tuned
                                 else "torch default"),
-                    mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs,
+                    mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs, rccl_ranks=rccl_ranks,
                     roofline=roof, kernels=kernels, mi355x_growmap=tuned, autoregressive_baseline=autoreg,
                     cpu_baseline=cpu)
         print(json.dumps(line))

@@ -103,7 +103,8 @@ def kv_checksum(engine):
 
 
 def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, prompt_len, max_steps, seed,
-             logit_gain=24.0, share_weights=0.0, out_dir=None):
+             logit_gain=24.0, share_weights=0.0, out_dir=None, seeded=False, share_vocab=0.0, compact=0,
+             branch_scale=1.0):
     """mode: 'stochastic' (SpecTree), 'greedy' (GreedyTree), 'specinfer' (SpecInferTree: draws with replacement)
     or 'greedys' (GreedySTree: greedy draft tree, target token sampled per node)."""
     RU = R["RU"]
@@ -123,8 +124,23 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
             noise = torch.randn_like(sd_t[k].float()) * sd_t[k].float().std() * share_weights
             sd_d[k].copy_((sd_t[k].float() + noise).half())
     arrays = {}
-    arrays.update(state_arrays(draft.engine.model, "draft"))
-    arrays.update(state_arrays(target.engine.model, "target"))
+    seeded_meta = None
+    if seeded:
+        # weights regenerated from seeds on both sides (oracle/seeded_weights.py) instead of stored in the trace
+        from oracle import seeded_weights as SW
+        sd_t = SW.seeded_state_dict(target_dims, vocab, 1000 + seed, logit_gain, branch_scale=branch_scale)
+        sd_d = SW.seeded_state_dict(draft_dims, vocab, 2000 + seed, logit_gain, branch_scale=branch_scale)
+        if share_vocab > 0.0:
+            SW.correlate(sd_d, sd_t, share_vocab, 3000 + seed)
+        for eng, sd in ((draft, sd_d), (target, sd_t)):
+            missing, unexpected = eng.engine.model.load_state_dict(sd, strict=False)
+            assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+        seeded_meta = dict(draft_seed=2000 + seed, target_seed=1000 + seed, share_vocab=share_vocab,
+                           share_seed=3000 + seed, branch_scale=branch_scale, draft_checksum=str(SW.checksum(sd_d)),
+                           target_checksum=str(SW.checksum(sd_t)))
+    else:
+        arrays.update(state_arrays(draft.engine.model, "draft"))
+        arrays.update(state_arrays(target.engine.model, "target"))
 
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -198,7 +214,10 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
                    vocab_size=vocab)
         if mode in ("stochastic", "specinfer"):
             arrays["r"] = tree.r.numpy().copy()
-            arrays["rand"] = tree.rand.numpy().copy()
+            if not compact:                       # compact traces regenerate `rand` from the noise seed (8 MB at V = 32000)
+                arrays["rand"] = tree.rand.numpy().copy()
+            else:
+                arrays["rand_probe"] = tree.rand[:, ::compact].numpy().copy()
         if mode == "specinfer":
             grow = tree.collective_grow_static
 
@@ -221,11 +240,13 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
             pre = f"step{step}"
             arrays[f"{pre}/gt"] = np.int64(gt)
             arrays[f"{pre}/tokens_pre"] = tree.tokens.numpy().copy()
-            arrays[f"{pre}/draft_logits_pre"] = tree.draft_logits[:n].numpy().copy()
+            dl_pre = tree.draft_logits[:n].numpy().copy()
+            arrays[f"{pre}/draft_logits_pre"] = dl_pre[:, ::compact] if compact else dl_pre
             for (lvl, ins, out) in samp_log:
-                arrays[f"{pre}/samp{lvl}/logits"] = ins[0]
-                if len(ins) > 1:
-                    arrays[f"{pre}/samp{lvl}/rand"] = ins[1]
+                if not compact:
+                    arrays[f"{pre}/samp{lvl}/logits"] = ins[0]
+                    if len(ins) > 1:
+                        arrays[f"{pre}/samp{lvl}/rand"] = ins[1]
                 arrays[f"{pre}/samp{lvl}/out"] = out
             step_box["i"] = step
             step_box["last_residual"] = None
@@ -238,10 +259,26 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
                 raw_box["logits"] = out
                 return out
             target.inference = spy
+            kvc = target.engine.kv_cache
+            orig_gather = kvc.gather_kv_incremental
+
+            def gather_spy(indices, offset):
+                raw_box["accepted_slots"] = [int(i_) for i_ in indices]
+                return orig_gather(indices, offset)
+            kvc.gather_kv_incremental = gather_spy
             valid, a, _, terminal = tree.verify()
             target.inference = orig_inf
+            kvc.gather_kv_incremental = orig_gather
             tl = raw_box["logits"][0]
-            arrays[f"{pre}/target_logits"] = tl[-n:].numpy().copy() if tl.shape[0] >= n else tl.numpy().copy()
+            tl_n = tl[-n:].numpy().copy() if tl.shape[0] >= n else tl.numpy().copy()
+            arrays[f"{pre}/target_logits"] = tl_n[:, ::compact] if compact else tl_n
+            if compact:
+                # full rows of the nodes the verifier walked (accepted path from the root): what the oracle's
+                # verifier needs to be pinned at this vocabulary size without storing [n, V] matrices
+                path_nodes = [0] + [s_ - (gt - 1) for s_ in raw_box.get("accepted_slots", [])]
+                arrays[f"{pre}/path_nodes"] = np.array(path_nodes, dtype=np.int64)
+                arrays[f"{pre}/path_target_rows"] = tl_n[path_nodes]
+                arrays[f"{pre}/path_draft_rows"] = dl_pre[path_nodes]
             arrays[f"{pre}/valid_tokens"] = valid.numpy().copy()
             arrays[f"{pre}/accept_len"] = np.int64(a)
             arrays[f"{pre}/terminal"] = np.int64(int(terminal))
@@ -250,7 +287,8 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
                 arrays[f"{pre}/residual"] = step_box["last_residual"]
             if mode == "greedys":
                 arrays[f"{pre}/target_token"] = step_box["target_token"]
-            arrays[f"{pre}/draft_logits_post"] = tree.draft_logits[:n].numpy().copy()
+            if not compact:
+                arrays[f"{pre}/draft_logits_post"] = tree.draft_logits[:n].numpy().copy()
             arrays[f"{pre}/kv_draft"] = kv_checksum(draft)
             arrays[f"{pre}/kv_target"] = kv_checksum(target)
             arrays[f"{pre}/position_ids_post"] = tree.position_ids.numpy().copy()
@@ -258,16 +296,17 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
             step += 1
         arrays["n_steps"] = np.int64(step)
         # final KV cache contents of the (small) draft cache, for exact compaction parity
-        arrays["final/draft_k"] = draft.engine.kv_cache.k_cache.numpy().copy()
-        arrays["final/target_k"] = target.engine.kv_cache.k_cache.numpy().copy()
-        arrays["final/target_v"] = target.engine.kv_cache.v_cache.numpy().copy()
+        if not compact:
+            arrays["final/draft_k"] = draft.engine.kv_cache.k_cache.numpy().copy()
+            arrays["final/target_k"] = target.engine.kv_cache.k_cache.numpy().copy()
+            arrays["final/target_v"] = target.engine.kv_cache.v_cache.numpy().copy()
     finally:
         torch.Tensor.multinomial = orig_multinomial
 
     meta = dict(name=name, growmap=os.path.relpath(growmap_path, REF), draft_dims=list(draft_dims),
                 target_dims=list(target_dims), vocab=vocab, M=M, T=T, mode=mode, prompt_len=prompt_len,
                 seed=seed, logit_gain=logit_gain, share_weights=share_weights, n_tree=int(n),
-                successors=g["Successors"], torch=torch.__version__)
+                successors=g["Successors"], torch=torch.__version__, seeded=seeded_meta, compact=int(compact))
     arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     out_dir = out_dir or os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
@@ -305,6 +344,12 @@ def gen_rows_fullvocab(R, out_dir):
 def main():
     R = import_reference()
     out_dir = os.path.join(REPO, "tests", "golden")
+    only = set(sys.argv[1:])                       # e.g. `python oracle/gen_golden.py D_160m13b V32k_seq128`
+    global run_case, gen_rows_fullvocab
+    if only:
+        _run, _rows = run_case, gen_rows_fullvocab
+        run_case = lambda R_, name, *a, **k: _run(R_, name, *a, **k) if name in only else None
+        gen_rows_fullvocab = lambda R_, d: _rows(R_, d) if "rows" in only else None
     # head dims are the ones the native attention kernel is built for (64 and 128)
     tiny = (128, 344, 2, 2, 2)      # hidden, inter, layers, heads, kv_heads  (D = 64)
     tiny_t = (256, 344, 2, 2, 2)    # D = 128
@@ -329,6 +374,18 @@ def main():
              logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
     run_case(R, "G_greedys", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "greedys", 20, 4, 23,
              logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
+    # config D: the 64-node 160m->13b growmap (levels 12/18/20/13); target with 5 heads of D = 128 like Llama-2-13b's
+    # 40 = 5 x 8 (an odd multiple); weights seeded, not stored
+    tiny_5h = (640, 344, 2, 5, 5)
+    run_case(R, "D_160m13b", gm("A100_growmaps/160m_13b/growmaps/A100-CNN-160m-13b-stochastic.pt"), tiny_5h, tiny_5h, 1024,
+             192, 0.6, "stochastic", 20, 5, 24, logit_gain=8.0, seeded=True, share_vocab=0.05, out_dir=out_dir)
+    # the real vocabulary: 68m-dims draft -> 160m-dims target, V = 32000, the config-B growmap; seeded weights,
+    # logits subsampled (every 16th column) + full rows of the walked path
+    d68 = (768, 3072, 2, 12, 12)
+    t160 = (768, 3072, 12, 12, 12)
+    run_case(R, "V32k_seq128", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), d68, t160, 32000,
+             384, 0.6, "stochastic", 32, 5, 25, logit_gain=10.0, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.005,
+             out_dir=out_dir)
     gen_rows_fullvocab(R, out_dir)
 
 

@@ -31,6 +31,7 @@ class InferenceEngine:
         weights = load_weights(model_name_or_path, dtype, device, **model_kw)
         self.model = self.model_cls(weights)
         self.model.eval()
+        self.model.ensure_rope(max_length)          # HF regrows its rotary cache past max_position_embeddings
         self.model_config = self.model.config
         self.kv_cache = KV_Cache(config=KVConfigView(weights.dims), max_length=max_length, device=device, dtype=dtype)
 

@@ -277,6 +277,13 @@ class _LlamaForCausalLM:
     def eval(self):
         return self
 
+    def ensure_rope(self, max_length: int):
+        """cos/sin tables cover max(max_position_embeddings, max_length) positions: the RoPE kernels index them by
+        position id unchecked, and an engine may be built with max_length beyond the config's table size."""
+        if max_length > self.cos.shape[0]:
+            self.cos, self.sin = rope_tables(self.dims.head_dim, max_length, self.dims.rope_theta, self.device,
+                                             self.dtype)
+
     @torch.no_grad()
     def forward(self, input_ids, max_length, storage_ids, attention_mask=None, position_ids=None, kv_cache=None,
                 debug=False, tree: TreeContext | None = None):

@@ -35,7 +35,8 @@ class GreedyTreeTest(GreedyTree):
                  sequence=None, new_tokens_buffer=None, parents_buffer=None, position_ids=None):
         self.max_width = max_width
         vocab = draft_model_engine.engine.model.vocab_size
-        gm = {"Successors": [list(range(1, max_width + 1))] + [[] for _ in range(max_width)]}
+        from .SpecTree import _star_growmap
+        gm = _star_growmap(max_width)
         super().__init__(draft_model_engine=draft_model_engine, target_model_engine=target_model_engine, prefix=prefix,
                          temperature=temperature, top_p=top_p, draft_kv_len=draft_kv_len, target_kv_len=target_kv_len,
                          max_length=max_length, device=device, max_target_seq=max_length, vocab_size=vocab, grow_map=gm,

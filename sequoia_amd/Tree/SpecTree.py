@@ -34,8 +34,15 @@ class SpecTree(NativeTree):
                                    self._bonus_uniform(), self.verify_ws, self.result)
 
 
+_STAR: dict = {}
+
+
 def _star_growmap(width: int) -> dict:
-    return {"Successors": [list(range(1, width + 1))] + [[] for _ in range(width)]}
+    """One growmap dict per width for the life of the process (the probe classes are rebuilt every step)."""
+    g = _STAR.get(width)
+    if g is None:
+        g = _STAR[width] = {"Successors": [list(range(1, width + 1))] + [[] for _ in range(width)]}
+    return g
 
 
 class SpecTreeTest(SpecTree):

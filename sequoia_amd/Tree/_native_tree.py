@@ -27,11 +27,14 @@ def _sync(device):
         torch.cuda.synchronize()
 
 
-# SpecTree / SpecInferTree commit order.  "reference" (default): bonus token stored before the accepted tokens are
-# gathered, like Tree/SpecTree.py:222-224 -- token parity with the reference, including its quirk that an accepted node
-# sitting at slot gt + n_accepted (e.g. the root's second child accepted alone) is committed with the bonus token's id.
-# "lossless": gather first, so the committed tokens are exactly the accepted ones (the algorithm as published).
-COMMIT_ORDER = os.environ.get("SEQUOIA_COMMIT_ORDER", "reference")
+# SpecTree / SpecInferTree commit order.  "lossless" (default): the accepted tokens are gathered first, then the bonus
+# token is stored, so the committed text is exactly the accepted path and agrees with the compacted KV rows (the
+# algorithm as published; an upstream bug fix).  "reference": bonus token stored BEFORE the gather, like
+# Tree/SpecTree.py:222-224 -- an accepted node sitting at slot gt + n_accepted (e.g. the root's second child accepted
+# alone) is then committed with the bonus token's id while its KV rows belong to the original token.  Only the
+# trace-parity tests (which replay runs of the reference itself) ask for it: SEQUOIA_COMMIT_ORDER=reference or
+# `tree.commit_order = "reference"`.
+COMMIT_ORDER = os.environ.get("SEQUOIA_COMMIT_ORDER", "lossless")
 
 
 class NativeTree(Tree):

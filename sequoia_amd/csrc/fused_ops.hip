@@ -13,7 +13,7 @@
 // FRAG: `out` is the fragment-major activation image of the tall-skinny linear layer (frag_chunk_offset, common.h)
 template <bool ADD, bool FRAG>
 __global__ void __launch_bounds__(ROW_THREADS)
-rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ res, half_t* __restrict__ sum_out,
+rmsnorm_kernel(const half_t* __restrict__ x, const half_t* res, half_t* sum_out,   // res and sum_out may alias
                const half_t* __restrict__ w, half_t* __restrict__ out, int hidden, float eps, int mtp) {
     __shared__ float s_f[ROW_WAVES];
     const size_t row = blockIdx.x;
@@ -167,9 +167,9 @@ extern "C" int sq_embed_rmsnorm_f16(const int64_t* d_ids, const void* embed, int
 // block reduction, so the kernel is one memory latency + one reduction deep (64 launches per 7B verify).
 template <int THREADS, int CPT, bool NORM>
 __global__ void __launch_bounds__(THREADS)
-rmsnorm_slabs_kernel(const float* __restrict__ slab, int splits, size_t split_stride, const half_t* __restrict__ res,
-                     half_t* __restrict__ sum_out, const half_t* __restrict__ w, half_t* __restrict__ out, int hidden,
-                     float eps, int frag_mtp) {
+rmsnorm_slabs_kernel(const float* __restrict__ slab, int splits, size_t split_stride, const half_t* res,
+                     half_t* sum_out,   // res and sum_out may alias
+                     const half_t* __restrict__ w, half_t* __restrict__ out, int hidden, float eps, int frag_mtp) {
     __shared__ float s_f[THREADS / 64];
     const size_t row = blockIdx.x;
     const int chunks = hidden >> 3;

@@ -216,8 +216,13 @@ static void ts_go(const TsParams& P, hipStream_t st) {
     constexpr int D = (MT * NT > 24) ? 3 : 4;
     const size_t lds = (size_t)TS_WAVES * ts_merge_tiles(MT, NT) * 16 * (NT * 16 + 4) * sizeof(float);
     auto kern = ts_linear_kernel<MT, NT, D, SILU>;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    static bool attr_done[16] = {};          // the attribute is per (function, device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 16) attr_done[dev] = true;
+    }
     hipLaunchKernelGGL(kern, dim3(P.tiles * P.splits), dim3(TS_THREADS), lds, st, P);
 }
 

@@ -34,8 +34,9 @@ def load_trace(name):
     return z, meta
 
 
-TRACE_NAMES = ["A_2chain", "B_seq128", "demo4", "C_greedy8x8", "E_64x2"]
-STOCHASTIC_TRACES = ["A_2chain", "B_seq128", "demo4", "E_64x2"]
+TRACE_NAMES = ["A_2chain", "B_seq128", "demo4", "C_greedy8x8", "E_64x2", "D_160m13b"]
+STOCHASTIC_TRACES = ["A_2chain", "B_seq128", "demo4", "E_64x2", "D_160m13b"]
+COMPACT_TRACES = ["V32k_seq128"]        # V = 32000, seeded weights, subsampled logits + full rows of the walked path
 BASELINE_TRACES = ["F_specinfer", "G_greedys"]        # the paper's comparison baselines (SpecInferTree, GreedySTree)
 
 

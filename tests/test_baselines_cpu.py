@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import load_trace
-from helpers import check_replay, replay_trace
+from helpers import assert_replay_complete, check_replay, replay_trace
 from oracle import ops_np as O
 from sequoia_amd.growmap import GrowMap
 
@@ -65,7 +65,7 @@ def test_native_loop_follows_reference_trace(oracle_ops, name):
     tolerance (asserted inside check_replay), committed tokens identical up to the first flipped draw."""
     steps, tree, draft, target, z, meta = replay_trace(name, "cpu")
     matched, diverged = check_replay(steps, z, meta)
-    assert matched >= 1, f"{name}: diverged at the very first step"
+    assert_replay_complete(name, steps, tree, z, meta, matched, diverged)
     if diverged is None:
         last = len(steps) - 1
         assert draft.engine.kv_cache.kv_offset == int(z[f"step{last}/kv_draft"][2])

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_trace
-from helpers import check_replay, replay_trace
+from helpers import assert_replay_complete, check_replay, replay_trace
 from oracle import ops_np as O
 from test_hip_kernels import csr, dev, random_tree
 
@@ -152,5 +152,5 @@ def test_greedys_target_draw_on_reference_trace(ops):
 def test_gpu_loop_follows_reference_trace(name):
     steps, tree, draft, target, z, meta = replay_trace(name, DEV)
     matched, diverged = check_replay(steps, z, meta)
-    assert matched >= 1, f"{name}: diverged at the very first step"
+    assert_replay_complete(name, steps, tree, z, meta, matched, diverged)
     print(f"{name}: {matched}/{int(z['n_steps'])} steps token-identical to the reference")

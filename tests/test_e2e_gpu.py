@@ -11,25 +11,24 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TRACE_NAMES, load_trace
-from helpers import build_engines, check_replay, make_tree, replay_trace
+from conftest import COMPACT_TRACES, TRACE_NAMES, load_trace
+from helpers import assert_replay_complete, build_engines, check_replay, make_tree, replay_trace
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("name", TRACE_NAMES)
+@pytest.mark.parametrize("name", TRACE_NAMES + COMPACT_TRACES)
 def test_gpu_loop_reproduces_reference_tokens(name):
+    """All steps of every trace (configs A-E shapes, the demo tree, and the V = 32000 trace).  Logits agree within
+    tolerance in every compared step (asserted inside check_replay); the committed tokens are identical in every
+    step -- a stochastic run may leave the reference only at a decision whose margin is proven to be inside one fp16
+    ulp (assert_replay_complete)."""
     steps, tree, draft, target, z, meta = replay_trace(name, DEV)
     matched, diverged = check_replay(steps, z, meta)
-    if meta["mode"] == "greedy":
-        assert diverged is None and matched == int(z["n_steps"])
-    else:
-        # logits agree within tolerance in every compared step (asserted inside check_replay);
-        # tokens are identical up to the first margin-limited decision, if any
-        assert matched >= 1, f"{name}: diverged at the very first step"
-        print(f"{name}: {matched}/{int(z['n_steps'])} steps token-identical to the reference"
-              + ("" if diverged is None else f" (margin-limited decision at step {diverged})"))
+    assert_replay_complete(name, steps, tree, z, meta, matched, diverged)
+    print(f"{name}: {matched}/{int(z['n_steps'])} steps token-identical to the reference"
+          + ("" if diverged is None else f" (margin-limited decision at step {diverged})"))
 
 
 def test_logits_close_to_reference_forward():

@@ -142,6 +142,8 @@ def _attn_case(rng, H, Hkv, D, M, gt, n, q_slot0, q_len):
     (32, 32, 128, 384, 129, 128, 128, 128),  # target verify of config B
     (8, 2, 128, 256, 40, 65, 0, 104),      # GQA, first verify call (prefix + tree)
     (8, 1, 128, 1024, 700, 129, 699, 129),  # config E shard: 8 q-heads on 1 KV head, long prefix
+    (40, 40, 128, 384, 140, 64, 139, 64),  # config D target verify: Llama-2-13b head count (40 = 5 x 8), 64-node tree
+    (16, 16, 128, 384, 140, 64, 152, 20),  # config D draft level (Sheared-LLaMA-1.3B: 16 heads of D = 128), level 3
 ])
 def test_tree_attention_vs_fp32_reference(ops, H, Hkv, D, M, gt, n, q_slot0, q_len):
     rng = np.random.RandomState(H * 7 + q_len)
