@@ -378,7 +378,7 @@ def main():
     # 40 = 5 x 8 (an odd multiple); weights seeded, not stored
     tiny_5h = (640, 344, 2, 5, 5)
     run_case(R, "D_160m13b", gm("A100_growmaps/160m_13b/growmaps/A100-CNN-160m-13b-stochastic.pt"), tiny_5h, tiny_5h, 1024,
-             192, 0.6, "stochastic", 20, 5, 24, logit_gain=8.0, seeded=True, share_vocab=0.05, out_dir=out_dir)
+             192, 0.6, "stochastic", 20, 5, 28, logit_gain=8.0, seeded=True, share_vocab=0.05, out_dir=out_dir)
     # the real vocabulary: 68m-dims draft -> 160m-dims target, V = 32000, the config-B growmap; seeded weights,
     # logits subsampled (every 16th column) + full rows of the walked path
     d68 = (768, 3072, 2, 12, 12)
