@@ -254,6 +254,9 @@ def main():
     ap.add_argument("--no-autoregressive", action="store_true", help="skip the target-only baseline (simulation_baseline)")
     ap.add_argument("--no-tuned-growmap", action="store_true",
                     help="skip the second timed loop on the growmap searched for this GPU (config B only)")
+    ap.add_argument("--sync-loop", action="store_true",
+                    help="drive every step from the host (reference API: construct_grow_map + verify with one result read "
+                         "per step) instead of the device-driven whole-step graphs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--selftest", action="store_true", help="launcher / aggregation check without a model (CPU-runnable)")
     args = ap.parse_args()
@@ -290,7 +293,8 @@ def main():
     prompts = load_prompts()[rank::world] if (world > 1 and not tp_mode) else load_prompts()
     if tp_mode:
         torch.manual_seed(17)          # identical noise on every rank: replicated decisions, no broadcast
-    loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs)
+    loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs,
+                pipelined=not args.sync_loop and not args.no_graphs)
 
     loop.run_steps(args.warmup)
     if world > 1:
@@ -349,7 +353,8 @@ def main():
             from sequoia_amd.growmap import GrowMap
             gm2 = GrowMap.load(tuned_name)
             draft.clear_kv(); target.clear_kv()
-            loop2 = Loop(cfg, draft, target, gm2, device, prompts, use_graphs=not args.no_graphs)
+            loop2 = Loop(cfg, draft, target, gm2, device, prompts, use_graphs=not args.no_graphs,
+                         pipelined=not args.sync_loop and not args.no_graphs)
             loop2.run_steps(args.warmup)
             s2, t2, k2 = loop2.run_steps(args.steps)
             tuned = dict(growmap=tuned_name, nodes=gm2.size, value=t2 / s2, unit="tokens/s", ms_per_step=s2 / k2 * 1e3,
@@ -376,6 +381,8 @@ def main():
                                          f"({gm.size}-node tree), T=0.6, top_p=1.0, M={cfg['M']}, 128-token c4_small "
                                          f"prompts, generate to 256",
                                 parallelism=(f"tp{world}" if tp_mode else ("replicas" if world > 1 else "single")), graphs=not args.no_graphs,
+                                step_loop="device-driven (one hipGraph per speculation step, results read one step late)"
+                                if loop.pipelined else "host-driven (one result read per step)",
                                 gemm="torch TunableOp (hipBLASLt/rocBLAS solution picked per shape)" if gemm_tuned
                                 else "torch default"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs, rccl_ranks=rccl_ranks,

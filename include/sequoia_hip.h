@@ -39,12 +39,23 @@ extern "C" {
 #define SQ_RESULT_INTS   64  /* header of the int32 step-result record, see below; the buffer
                                 passed as d_result holds SQ_RESULT_INTS + n_tree ints            */
 
+/* Device-resident state of the device-driven speculation step (int32[SQ_STEP_INTS], owned by the caller): with it no
+ * launch argument of a speculation step depends on the step, so construct_grow_map() + verify() + the next step's
+ * preparation (Tree/SpecTree.py:245-281) replay as ONE hipGraph and the host reads the result record one step late. */
+#define SQ_STEP_GT        0  /* ground_truth_len the current step runs with                                     */
+#define SQ_STEP_NEXT_GT   1  /* written by sq_verify_*: gt of the next step (a + 1), or gt when terminal        */
+#define SQ_STEP_INDEX     2  /* step counter: indexes the bonus-uniform table and the result ring               */
+#define SQ_STEP_ACTIVE    3  /* cleared by sq_verify_* on a terminal step                                       */
+#define SQ_STEP_INTS      8
+#define SQ_RESULT_RING    4  /* d_result_ring holds SQ_RESULT_RING records of SQ_RESULT_INTS ints, slot = index % ring */
+
 /* Step-result record written by sq_verify_* (device memory, int32[SQ_RESULT_INTS]).        */
 #define SQ_RES_ACCEPT_LEN 0  /* a = len(accept_list) = gt + #accepted tree nodes            */
 #define SQ_RES_N_TREE     1  /* #accepted tree nodes                                        */
 #define SQ_RES_BONUS      2  /* bonus token id written to tokens[a], -1 when terminal       */
 #define SQ_RES_TERMINAL   3  /* 0 / 1                                                       */
-#define SQ_RES_REASON     4  /* 0 none, 1 EOS token accepted, 2 NaN residual                */
+#define SQ_RES_REASON     4  /* 0 none, 1 EOS token accepted, 2 NaN residual, 3 no slot left for the bonus token
+                                (a >= token_capacity: the reference raises IndexError, Tree/SpecTree.py:222)  */
 #define SQ_RES_GT         5  /* echo of the ground_truth_len the step ran with              */
 #define SQ_RES_LAST_NODE  6  /* tree-local id of the node the walk stopped at               */
 #define SQ_RES_SLOTS      8  /* [8, 8+min(N_TREE,56)): absolute slots of the accepted nodes  */
@@ -84,10 +95,12 @@ int sq_kv_scatter_f16(void* k_layer, void* v_layer, const void* new_k, const voi
  * (layer, head) tile happen before its writes, so overlapping src/dst is safe);
  * then rows [dst_offset+count, zero_end) are zeroed (zero_end <= m; pass zero_end = m for the
  * reference's full-tail clear, gt+n-1 for dirty-range only, 0 for none).
- * count = *d_count if d_count != NULL else max_count.  slots are ascending absolute slots.   */
+ * count = *d_count if d_count != NULL else max_count.  slots are ascending absolute slots.
+ * d_dst_offset (optional, device int32) overrides dst_offset with a value read on the device (the device-driven
+ * step's ground-truth length); zero_end must be 0 then.                                                          */
 int sq_kv_compact_f16(void* k_cache, void* v_cache, int n_layers, int h_kv, int m, int d,
                       const int32_t* d_slots, const int32_t* d_count, int max_count,
-                      int dst_offset, int zero_end, void* stream);
+                      int dst_offset, int zero_end, const int32_t* d_dst_offset, void* stream);
 
 /* KV_Cache.clear (Engine/Llama_KV.py:91-94) restricted to rows [0, used_rows) of every
  * (layer, head): rows never written are already zero.                                       */
@@ -153,7 +166,29 @@ int sq_stage_inputs(int64_t* dst_ids, const int64_t* src_ids, int64_t* dst_pos, 
                     int64_t* dst_storage, const int64_t* src_storage, int q_len, int32_t* d_ctx, int q_slot0, int gt,
                     int kv_len, void* stream);
 
+/* The same staging for the device-driven step: queries at slots [gt + rel_slot0, gt + rel_slot0 + q_len) with
+ * gt = d_step[SQ_STEP_GT]; ids from `tokens`, storage ids = slots, position ids = slot for committed text and
+ * d_depth[t] + gt - 1 for tree node t (Tree/SpecTree.py:61,264-270), d_ctx = {q_slot0, gt, gt + rel_kv_len}.
+ * advance != 0 first moves d_step to the next step (gt <- next_gt, index += 1).                                    */
+int sq_stage_tree_inputs(int64_t* dst_ids, int64_t* dst_pos, int64_t* dst_storage, int32_t* d_ctx,
+                         const int64_t* tokens, const int32_t* d_depth, int n_tree, int q_len, int rel_slot0,
+                         int rel_kv_len, int32_t* d_step, int advance, void* stream);
+
 /* ---- a2: draft expansion samplers ------------------------------------------------------- */
+/* Every logits row is processed by ceil(V / 4096) workgroups ("parts"): per-part softmax statistics, keys + local top-k
+ * per part, one-wave merge per row -- a tree level of 1-34 rows runs on 8-272 compute units.  Scratch is caller-owned:
+ * sq_sample_workspace_bytes(n_rows, vocab, k) bytes, reusable by every later sampler call on the same stream.      */
+size_t sq_sample_workspace_bytes(int n_rows, int vocab, int k);
+
+/* Per-part statistics of softmax(logits / T): d_stats[(row * parts + p) * 2 + {0, 1}] = {max_p h(x/T), sum_p exp(. - max_p)}
+ * with parts = ceil(V / 4096); `row` is the launch row r (stats_by_source_row == 0) or the source row d_row_ids[r]
+ * (!= 0: a table indexed like the logits matrix).  copy_dst != NULL additionally copies launch row r to
+ * copy_dst + r * ld_dst (the speculation step uses this launch instead of the copy
+ * `draft_logits[first:first+total] = logits[-total:]`, Tree/SpecTree.py:121).                                       */
+int sq_logits_stats_f16(const void* logits, int64_t ld, const int32_t* d_row_ids, int n_rows, int vocab,
+                        float temperature, float* d_stats, int stats_by_source_row, void* copy_dst, int64_t ld_dst,
+                        void* stream);
+
 /* utils.sampling_without_replacement (utils.py:10-18) for n_rows rows:
  * q = softmax(logits/T) (fp16), key = log(u)/q (fp16), take the k largest keys per row in
  * descending order (ties: lower token id first).
@@ -161,17 +196,21 @@ int sq_stage_inputs(int64_t* dst_ids, const int64_t* src_ids, int64_t* dst_pos, 
  * rand likewise with ld_rand.  Output, int64:
  *   d_branch == NULL : out[r*k + s] = s-th sample of row r               (callable contract)
  *   d_branch != NULL : out[d_out_off[r] + s] for s < d_branch[r]          (fused gather,
- *                      = tokens[num_nodes:...] = new[sample_gather_indices], SpecTree.py:104) */
+ *                      = tokens[num_nodes:...] = new[sample_gather_indices], SpecTree.py:104)
+ * d_out_base (optional, device int32): element offset added to every output index, read on the device -- the
+ *   speculation step passes its device-resident ground-truth length so that no launch argument depends on the step.
+ * d_stats (optional): statistics of the SOURCE rows from an earlier sq_logits_stats_f16(..., stats_by_source_row = 1)
+ *   over the same logits matrix; NULL = computed here (one more launch).                                             */
 int sq_sample_wor_f16(const void* logits, int64_t ld_logits, const void* rand, int64_t ld_rand,
                       const int32_t* d_row_ids, int n_rows, int vocab, int k, float temperature,
                       int64_t* out, const int32_t* d_branch, const int32_t* d_out_off,
-                      void* stream);
+                      const int32_t* d_out_base, const float* d_stats, void* workspace, void* stream);
 
 /* utils.sampling_argmax (utils.py:29-32): top-k token ids of the raw logits, descending,
  * ties: lower token id first.  Same addressing / output modes as sq_sample_wor_f16.          */
 int sq_topk_f16(const void* logits, int64_t ld_logits, const int32_t* d_row_ids, int n_rows,
                 int vocab, int k, int64_t* out, const int32_t* d_branch,
-                const int32_t* d_out_off, void* stream);
+                const int32_t* d_out_off, const int32_t* d_out_base, void* workspace, void* stream);
 
 /* ---- a6/a7/a8: verification ------------------------------------------------------------- */
 size_t sq_verify_workspace_bytes(int n_tree);
@@ -193,14 +232,22 @@ size_t sq_verify_workspace_bytes(int n_tree);
  *   draft_logits rows of the walked nodes get the -65504 writes           (:156)
  *   result record filled (see SQ_RES_*).
  * target_logits: fp16 [n_tree][V]; draft_logits: fp16 [>= n_tree][V] (tree-local rows);
- * tokens: int64 [M]; r: fp16 [M]; children CSR over tree-local ids.                          */
+ * tokens: int64 [token_capacity]; r: fp16 [M]; children CSR over tree-local ids.
+ * token_capacity > 0: a step whose bonus slot a would lie outside the token buffer is made terminal (reason 3)
+ *   instead of writing out of bounds (the reference raises IndexError there); 0 = unchecked.
+ * Device-driven step (d_step != NULL, see SQ_STEP_*): gt is read from d_step[SQ_STEP_GT] (the `gt` argument is
+ *   ignored), the bonus uniform is d_bonus_u24[d_step[SQ_STEP_INDEX] % n_bonus] when d_bonus_u24 != NULL (else
+ *   bonus_u24; its flag bits always apply), the walker writes d_step[SQ_STEP_NEXT_GT] and clears
+ *   d_step[SQ_STEP_ACTIVE] on a terminal step, and copies the record header to slot index % SQ_RESULT_RING of
+ *   d_result_ring (optional) for a host that reads results one step late.                                        */
 #define SQ_VERIFY_GATHER_FIRST 0x80000000u
 int sq_verify_stochastic_f16(const void* target_logits, void* draft_logits,
-                             int64_t* tokens, const void* r,
+                             int64_t* tokens, int token_capacity, const void* r,
                              const int32_t* d_child_off, const int32_t* d_child_ids,
                              int n_tree, int vocab, int gt, float temperature,
                              uint32_t bonus_u24, void* workspace, int32_t* d_result,
-                             void* stream);
+                             int32_t* d_step, const uint32_t* d_bonus_u24, int n_bonus,
+                             int32_t* d_result_ring, void* stream);
 
 /* utils.get_sampling_logits (utils.py:65-77), applied by SpecTree.verify to the target logits
  * before the softmax (Tree/SpecTree.py:196): in place, rows [n_rows][ld]; a token is set to -inf
@@ -213,10 +260,10 @@ int sq_top_p_filter_f16(void* logits, int64_t ld, int n_rows, int vocab, float t
  * walk by token equality, bonus = target argmax at the last accepted node.  tokens are only
  * compacted / bonus written when not terminal... the compaction tokens[:a] happens always
  * (:204), the bonus write only when not terminal (:206-207).                                */
-int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens,
+int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens, int token_capacity,
                          const int32_t* d_child_off, const int32_t* d_child_ids,
                          int n_tree, int vocab, int gt, void* workspace, int32_t* d_result,
-                         void* stream);
+                         int32_t* d_step, int32_t* d_result_ring, void* stream);
 
 /* ---- the comparison baselines of the paper on the same kernels ------------ */
 /* SpecInferTree.collective_grow_static (Tree/SpecInferTree.py:104-109): k draws WITH replacement per
@@ -232,16 +279,16 @@ int sq_sample_iid_f16(const void* logits, int64_t ld, const int32_t* d_row_ids, 
  * only replaces p by the residual -- q keeps the rejected token (the children were drawn with
  * replacement) and the draft logits are not modified.                                           */
 int sq_verify_specinfer_f16(const void* target_logits, const void* draft_logits, int64_t* tokens,
-                            const void* r, const int32_t* d_child_off, const int32_t* d_child_ids,
+                            int token_capacity, const void* r, const int32_t* d_child_off, const int32_t* d_child_ids,
                             int n_tree, int vocab, int gt, float temperature, uint32_t bonus_u24,
                             void* workspace, int32_t* d_result, void* stream);
 
 /* GreedySTree.verify (Tree/GreedySTree.py:188-214): the walk of sq_verify_greedy_f16 against one
  * target token per node supplied by the caller (sampled from the target distribution instead of
  * the argmax); bonus = the target token of the last accepted node.  d_target_tokens: int64 [n_tree]. */
-int sq_verify_tokens_f16(const int64_t* d_target_tokens, int64_t* tokens, const int32_t* d_child_off,
-                         const int32_t* d_child_ids, int n_tree, int gt, void* workspace,
-                         int32_t* d_result, void* stream);
+int sq_verify_tokens_f16(const int64_t* d_target_tokens, int64_t* tokens, int token_capacity,
+                         const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int gt,
+                         void* workspace, int32_t* d_result, void* stream);
 
 /* ---- row-wise glue of the Llama block (launch removal on the draft side) --- */
 /* LlamaRMSNorm_FI.forward (Engine/Llama_modules.py:274-288): fp32 variance, normalised value

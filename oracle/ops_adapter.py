@@ -33,7 +33,9 @@ class OracleOps:
     def kv_scatter(self, k_layer, v_layer, new_k, new_v, storage_ids):
         O.kv_scatter(_np(k_layer), _np(v_layer), _np(new_k), _np(new_v), _np(storage_ids))
 
-    def kv_compact(self, k_cache, v_cache, slots, count, max_count, dst_offset, zero_end):
+    def kv_compact(self, k_cache, v_cache, slots, count, max_count, dst_offset, zero_end, dst_offset_dev=None):
+        if dst_offset_dev is not None:
+            dst_offset = int(dst_offset_dev.reshape(-1)[0])
         c = max_count if count is None else min(int(count.reshape(-1)[0]), max_count)
         sl = [int(s) for s in _np(slots)[:c]] if c > 0 else []
         O.kv_compact(_np(k_cache)[:, 0], _np(v_cache)[:, 0], sl, dst_offset, zero_end)
@@ -49,6 +51,34 @@ class OracleOps:
     def store_i32(self, dst, values):
         for i, v in enumerate(values):
             dst[i] = int(v)
+
+    def stage_tree_inputs(self, dst_ids, dst_pos, dst_storage, ctx, tokens, depth, n_tree, rel_slot0, rel_kv_len, step,
+                          advance=False):
+        """sq_stage_tree_inputs (csrc/kv_ops.hip) restated: the device-driven step's input staging."""
+        gt = int(step[1] if advance else step[0])
+        q_len = dst_ids.numel()
+        slots = np.arange(gt + rel_slot0, gt + rel_slot0 + q_len)
+        t = slots - (gt - 1)
+        d = _np(depth)
+        pos = np.where((t >= 0) & (t < n_tree), d[np.clip(t, 0, n_tree - 1)].astype(np.int64) + gt - 1, slots)
+        dst_ids.reshape(-1).copy_(tokens[torch.from_numpy(slots)])
+        dst_storage.reshape(-1).copy_(torch.from_numpy(slots))
+        dst_pos.reshape(-1).copy_(torch.from_numpy(pos))
+        ctx[0], ctx[1], ctx[2] = gt + rel_slot0, gt, gt + rel_kv_len
+        if advance:
+            step[0] = gt
+            step[2] = int(step[2]) + 1
+
+    @staticmethod
+    def stats_shape(n_rows, vocab):
+        return (n_rows, (vocab + 4095) // 4096, 2)
+
+    def logits_stats(self, logits, temperature, stats, row_ids=None, by_source_row=False, copy_dst=None):
+        """The oracle's samplers compute their own softmax statistics: only the row copy is performed."""
+        if copy_dst is not None:
+            rows = _np(row_ids).astype(np.int64) if row_ids is not None else np.arange(logits.shape[0])
+            copy_dst[:len(rows)].copy_(logits[torch.from_numpy(rows)])
+        return stats
 
     def tree_attention(self, q, k_layer, v_layer, out, kv_len, scale, dense_mask=None, q_slot0=0, gt=0, n_tree=0,
                        bitmask=None, ctx=None):
@@ -76,8 +106,10 @@ class OracleOps:
                                    bitmask=bitmask)
 
     @staticmethod
-    def _emit(samples, out, branch, out_off):
+    def _emit(samples, out, branch, out_off, out_base=None):
         o = _np(out)
+        if out_base is not None:
+            o = o[int(out_base.reshape(-1)[0]):]
         if branch is None:
             o[:samples.size] = samples.reshape(-1)
         else:
@@ -85,14 +117,14 @@ class OracleOps:
             for r in range(samples.shape[0]):
                 o[off[r]:off[r] + br[r]] = samples[r, :br[r]]
 
-    def sample_wor(self, logits, rand, row_ids, k, temperature, out, branch=None, out_off=None):
+    def sample_wor(self, logits, rand, row_ids, k, temperature, out, branch=None, out_off=None, out_base=None, stats=None):
         rows = _np(row_ids).astype(np.int64) if row_ids is not None else np.arange(logits.shape[0])
-        self._emit(O.sample_wor(_np(logits)[rows], _np(rand)[rows], k, temperature), out, branch, out_off)
+        self._emit(O.sample_wor(_np(logits)[rows], _np(rand)[rows], k, temperature), out, branch, out_off, out_base)
         return out
 
-    def topk(self, logits, row_ids, k, out, branch=None, out_off=None):
+    def topk(self, logits, row_ids, k, out, branch=None, out_off=None, out_base=None):
         rows = _np(row_ids).astype(np.int64) if row_ids is not None else np.arange(logits.shape[0])
-        self._emit(O.topk_ids(_np(logits)[rows], k), out, branch, out_off)
+        self._emit(O.topk_ids(_np(logits)[rows], k), out, branch, out_off, out_base)
         return out
 
     def verify_workspace(self, n_tree, device):
@@ -109,12 +141,32 @@ class OracleOps:
                 r[8 + j] = s
             r[64 + j] = s
 
+    @staticmethod
+    def _step_out(step, result, result_ring, res):
+        """What the walker writes for the device-driven step (csrc/verify.hip): next gt, active flag, ring record."""
+        if step is None:
+            return
+        r = _np(result)
+        r[7] = int(step[2])
+        step[1] = res["gt"] if res["terminal"] else res["accept_len"] + 1
+        if res["terminal"]:
+            step[3] = 0
+        if result_ring is not None:
+            slot = int(step[2]) % 4
+            _np(result_ring)[slot * 64:(slot + 1) * 64] = r[:64]
+
     def verify_stochastic(self, target_logits, draft_logits, tokens, r, child_off, child_ids, n_tree, gt, temperature,
-                          u24, workspace, result):
+                          u24, workspace, result, step=None, bonus_table=None, result_ring=None):
         succ = _succ_from_csr(child_off, child_ids, n_tree)
+        uni = int(u24) & 0xffffff
+        if step is not None:
+            gt = int(step[0])
+            if bonus_table is not None:
+                uni = int(bonus_table[int(step[2]) % bonus_table.numel()]) & 0xffffff
         res = O.verify_stochastic(_np(target_logits), _np(draft_logits), _np(tokens), _np(r), succ, gt, temperature,
-                                  int(u24) & 0xffffff, gather_first=bool(int(u24) & 0x80000000))
+                                  uni, gather_first=bool(int(u24) & 0x80000000))
         self._fill(result, res)
+        self._step_out(step, result, result_ring, res)
         return result
 
     def sample_iid(self, logits, u24, row_ids, k, temperature, out, branch=None, out_off=None):
@@ -141,9 +193,14 @@ class OracleOps:
             logits.copy_(torch.from_numpy(O.top_p_filter(_np(logits), top_p, temperature)))
         return logits
 
-    def verify_greedy(self, target_logits, tokens, child_off, child_ids, n_tree, gt, workspace, result):
+    def verify_greedy(self, target_logits, tokens, child_off, child_ids, n_tree, gt, workspace, result, step=None,
+                      result_ring=None):
         succ = _succ_from_csr(child_off, child_ids, n_tree)
-        self._fill(result, O.verify_greedy(_np(target_logits), _np(tokens), succ, gt))
+        if step is not None:
+            gt = int(step[0])
+        res = O.verify_greedy(_np(target_logits), _np(tokens), succ, gt)
+        self._fill(result, res)
+        self._step_out(step, result, result_ring, res)
         return result
 
     # row-wise glue: the reference's fp16/fp32 expressions (Engine/Llama_modules.py:274-288, 270-271)

@@ -79,6 +79,28 @@ class InferenceEngineTG(InferenceEngine):
         super().__init__(max_length, model_name_or_path, dtype, device, **model_kw)
 
 
+_PRIMED: dict = {}
+
+
+def prime_graph_rng(device):
+    """The first hipGraph capture of a process registers the default generator and allocates its capture-state tensors
+    in whatever mode is active then; if that is inference mode (all captures of this package are), every later capture
+    OUTSIDE inference mode -- user code, a benchmark harness -- fails with "Inplace update to inference tensor".  One
+    empty graph captured in normal mode first, and kept alive, pins those tensors as ordinary ones."""
+    key = str(device)
+    if key in _PRIMED or not str(device).startswith("cuda"):
+        return
+    with torch.inference_mode(False):
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(device=device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                pass
+        torch.cuda.current_stream(device).wait_stream(s)
+    _PRIMED[key] = g
+
+
 class _GraphRunner:
     """One captured forward of fixed q_len: static input buffers + a hipGraph (the analogue of
     the reference's capture_graph closure, Engine/Engine.py:127-166)."""
@@ -86,6 +108,7 @@ class _GraphRunner:
     def __init__(self, engine: InferenceEngine, q_len: int, mempool, n_warmups: int, mode: str, n_tree: int = 1,
                  bitmask=None):
         dev, M = engine.device, engine.max_length
+        prime_graph_rng(dev)
         self.engine, self.q_len, self.mode = engine, q_len, mode
         self.input_ids = torch.zeros((1, q_len), dtype=torch.long, device=dev)
         self.position_ids = torch.zeros((1, q_len), dtype=torch.long, device=dev)

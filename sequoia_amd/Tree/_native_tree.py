@@ -17,7 +17,8 @@ import time
 import torch
 
 from ..Engine.Llama_modules import TreeContext
-from ..native import (SQ_VERIFY_GATHER_FIRST, SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_TERMINAL, SQ_RESULT_INTS)
+from ..native import (SQ_VERIFY_GATHER_FIRST, SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_TERMINAL, SQ_RESULT_INTS,
+                      SQ_RESULT_RING)
 from ..ops import get_ops
 from .Tree import Tree, growmap_on_device
 
@@ -35,6 +36,9 @@ def _sync(device):
 # trace-parity tests (which replay runs of the reference itself) ask for it: SEQUOIA_COMMIT_ORDER=reference or
 # `tree.commit_order = "reference"`.
 COMMIT_ORDER = os.environ.get("SEQUOIA_COMMIT_ORDER", "lossless")
+# Device-driven step (Tree/step_graph.py): "1" = every tree adopts the static step buffers and can run pipelined steps
+# (enqueue_step / collect_step); the synchronous reference API (construct_grow_map / verify) works either way.
+STEP_GRAPH = os.environ.get("SEQUOIA_STEP_GRAPH", "0") == "1"
 
 
 class NativeTree(Tree):
@@ -44,7 +48,8 @@ class NativeTree(Tree):
                  top_p: float = 0.9, draft_kv_len=0, target_kv_len=0, max_length=256, device: str = "cpu",
                  max_target_seq=256, vocab_size=32000, grow_map=None, attn_mask=None, sequence=None,
                  new_tokens_buffer=None, parents_buffer=None, position_ids=None, residual_graph=None,
-                 sampling_callables=None, sample_gather_indices=None, bonus_uniforms=None) -> None:
+                 sampling_callables=None, sample_gather_indices=None, bonus_uniforms=None, step_graph=None,
+                 commit_order=None) -> None:
         super().__init__(device=device, max_length=max_length)
         assert self.max_length == draft_model_engine.engine.max_length
         self.ops = get_ops()
@@ -63,6 +68,20 @@ class NativeTree(Tree):
         self.draft_step = self.gm.draft_step
         self.Successors = self.gm.successors
         self.tree_size = self.gm.size
+        self.commit_order = commit_order or COMMIT_ORDER
+        # device-driven step: adopt the static buffers of this (engines, growmap, parameters) combination; the
+        # launch sequence is captured on the first fresh prompt (both caches empty), before the prefill below
+        self.state = None
+        want_state = STEP_GRAPH if step_graph is None else bool(step_graph)
+        if want_state and sampling_callables is None and hasattr(target_model_engine.engine, "model_run"):
+            from .step_graph import StepState
+            st = StepState.get(self)
+            if draft_kv_len == 0 and target_kv_len == 0:
+                st.ensure_captured()
+            if st.graph is not None or not st.cuda:
+                st.reset()
+                self.state = st
+                self.tokens = st.tokens
         self.initialize(attn_mask, sequence, new_tokens_buffer, parents_buffer, position_ids, None)
         self.set_prefix(prefix=prefix)
         n, gt = self.tree_size, len(prefix)
@@ -72,6 +91,9 @@ class NativeTree(Tree):
         if self.stochastic:
             # same CPU-generator draws, in the same order, as the reference (Tree/SpecTree.py:60,84)
             self.r = torch.rand(len(position_ids), dtype=self.dtype).to(self.device)
+            if self.state is not None:
+                self.state.r[:len(self.r)].copy_(self.r)
+                self.r = self.state.r
         self.depth = self.gdev["depth"][1:]
         self.position_ids[gt: gt + n - 1] = self.depth + (gt - 1)
         self.storage_ids = torch.arange(self.max_length, device=self.device)
@@ -82,7 +104,8 @@ class NativeTree(Tree):
             for eng in (draft_model_engine, target_model_engine):
                 if getattr(eng, "requested_graph_lengths", None) and hasattr(eng, "ensure_tree_graphs"):
                     eng.ensure_tree_graphs(self.gdev["bitmask"], n)
-        self.draft_logits = torch.zeros((max(n, 1), vocab_size), dtype=self.dtype, device=self.device)
+        self.draft_logits = (self.state.draft_logits if self.state is not None else
+                             torch.zeros((max(n, 1), vocab_size), dtype=self.dtype, device=self.device))
 
         logits = self.draft_model_engine.inference(
             input_ids=self.tokens[draft_kv_len:self.num_nodes].unsqueeze(0),
@@ -99,9 +122,16 @@ class NativeTree(Tree):
             self.bonus_u24 = [int(x) for x in bonus_uniforms]
         self.step_idx = 0
         self._no_room = None
-        self.commit_order = COMMIT_ORDER
-        self.verify_ws = self.ops.verify_workspace(n, self.device)
-        self.result = torch.zeros(SQ_RESULT_INTS + n, dtype=torch.int32, device=self.device)
+        if self.state is not None:
+            self.verify_ws, self.result = self.state.verify_ws, self.state.result
+            if self.stochastic:
+                nb = self.state.bonus.numel()
+                tab = [self.bonus_u24[i % len(self.bonus_u24)] for i in range(nb)]
+                self.state.bonus.copy_(torch.tensor(tab, dtype=torch.int32))
+        else:
+            self.verify_ws = self.ops.verify_workspace(n, self.device)
+            self.result = torch.zeros(SQ_RESULT_INTS + n, dtype=torch.int32, device=self.device)
+        self._pipe = None
         self.seq_to_use = list(range(self.max_length))
         self.target_logits = None
 
@@ -109,7 +139,12 @@ class NativeTree(Tree):
     def _init_draft_noise(self, n: int, vocab_size: int):
         """Per-prompt noise of the draft expansion: the [n, V] uniforms of sampling without replacement
         (Tree/SpecTree.py:84), drawn on the CPU generator right after `r` like the reference."""
-        self.rand = torch.empty((n, vocab_size), dtype=self.dtype).uniform_().to(self.device)
+        rand = torch.empty((n, vocab_size), dtype=self.dtype).uniform_()
+        if self.state is not None and self.state.rand is not None:
+            self.state.rand.copy_(rand)
+            self.rand = self.state.rand
+        else:
+            self.rand = rand.to(self.device)
 
     def _ctx(self, q_slot0: int, kv_len: int) -> TreeContext:
         # storage_ids = arange(M) (Tree/SpecTree.py:63): the queries' KV slots are q_slot0 + arange(q_len)
@@ -243,3 +278,99 @@ class NativeTree(Tree):
         self.target_kv_len = a
 
     _compact_when_terminal = True
+
+    # ---- device-driven steps (Tree/step_graph.py) ------------------------------------------------------------------
+    def begin_pipeline(self):
+        """Hand the loop to the device: the step block takes over the ground-truth length.  Legal once the target is
+        prefilled (after at least one synchronous step) and when the next step has room."""
+        st = self.state
+        if st is None:
+            raise RuntimeError("this tree has no step state (construct it with step_graph=True / SEQUOIA_STEP_GRAPH=1)")
+        if self.target_kv_len == 0 or self._no_room:
+            raise RuntimeError("begin_pipeline() needs a prefilled target (run one synchronous step) and room for a step")
+        import collections
+        gt = self.ground_truth_len
+        block = torch.zeros(st.step.numel(), dtype=torch.int32)
+        block[0], block[1], block[2], block[3] = gt, gt, self.step_idx, 1
+        st.step.copy_(block)
+        if self.stochastic:      # statistics of the root's draft row (the synchronous path does not keep them)
+            self.ops.logits_stats(self.draft_logits[0:1], self.temperature, st.stats[0:1])
+        self._pipe = dict(inflight=collections.deque(), gt_known=gt, next_idx=self.step_idx, dead=False)
+
+    def can_enqueue(self, horizon: int) -> bool:
+        """True when one more step may be enqueued without knowing the results of the steps still in flight: even if
+        each of them commits a full path the tree and the bonus token fit the buffers and the sequence stays below
+        `horizon` tokens (the caller's stopping length)."""
+        p = self._pipe
+        per_step = self.gdev["max_depth"] + 1
+        gt_max = p["gt_known"] + per_step * len(p["inflight"])
+        n = self.tree_size
+        return (not p["dead"] and gt_max < horizon and gt_max + n - 1 <= self.max_length
+                and gt_max + per_step <= self.max_length)
+
+    def enqueue_step(self):
+        st, p = self.state, self._pipe
+        idx = p["next_idx"]
+        st.launch()
+        if st.cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            slot = idx % st.host_ring.shape[0]
+            with torch.cuda.stream(st.copy_stream):
+                st.copy_stream.wait_event(ev)
+                st.host_ring[slot].copy_(st.ring[slot * SQ_RESULT_INTS:(slot + 1) * SQ_RESULT_INTS], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+            p["inflight"].append((idx, done))
+        else:
+            p["inflight"].append((idx, None))
+        p["next_idx"] = idx + 1
+
+    def collect_step(self):
+        """Result of the oldest step in flight: (accept_length, n_accepted, bonus_token, terminal).  Blocks only until
+        that step's 256-byte record has reached the host (the copy runs beside the following step)."""
+        st, p = self.state, self._pipe
+        idx, done = p["inflight"].popleft()
+        slot = idx % SQ_RESULT_RING
+        if done is not None:
+            done.synchronize()
+            rec = st.host_ring[slot]
+        else:
+            rec = st.ring[slot * SQ_RESULT_INTS:(slot + 1) * SQ_RESULT_INTS]
+        a, n_acc, bonus, terminal = int(rec[SQ_RES_ACCEPT_LEN]), int(rec[SQ_RES_N_TREE]), int(rec[2]), bool(rec[SQ_RES_TERMINAL])
+        assert int(rec[7]) == idx, f"result ring slot {slot} holds step {int(rec[7])}, expected {idx}"
+        self.last_result = rec
+        self.step_idx = idx + 1
+        if terminal:
+            p["dead"] = True
+        else:
+            p["gt_known"] = a + 1
+        self._sync_host_state(a, terminal)
+        return a, n_acc, bonus, terminal
+
+    def _sync_host_state(self, a: int, terminal: bool):
+        """Host mirrors of what the device step did (the synchronous API keeps working after a pipelined stretch)."""
+        new_gt = a if terminal else a + 1
+        n = self.tree_size
+        self.ground_truth_len = new_gt
+        self.num_nodes = new_gt
+        self.draft_kv_len = new_gt
+        self.target_kv_len = new_gt - 1
+        dkv, tkv = self.draft_model_engine.engine.kv_cache, self.target_model_engine.engine.kv_cache
+        dkv.kv_offset, tkv.kv_offset = new_gt, new_gt - 1
+        dkv.dirty_end = max(dkv.dirty_end, new_gt + n - 1); tkv.dirty_end = max(tkv.dirty_end, new_gt + n - 1)
+        if new_gt + n - 1 > self.max_length:
+            self._no_room = f"{new_gt} committed tokens + tree ({n}) exceed max_length {self.max_length} (README.md:47)"
+
+    def end_pipeline(self):
+        """Drain the steps still in flight and restore the host-side buffers the synchronous path reads."""
+        p = self._pipe
+        if p is None:
+            return
+        while p["inflight"]:
+            self.collect_step()
+        gt, n = self.ground_truth_len, self.tree_size
+        self.position_ids[:gt] = self._arange[:gt]
+        if gt + n - 1 <= self.max_length:
+            torch.add(self.depth, gt - 1, out=self.position_ids[gt:gt + n - 1])
+        self._pipe = None

@@ -1,0 +1,180 @@
+"""Device-driven speculation step: construct_grow_map() + verify() + the next step's preparation
+(Tree/SpecTree.py:245-281, tests/testbed.py:80-87) as ONE launch sequence in which no launch argument depends on the
+step.  The ground-truth length lives in a device block (include/sequoia_hip.h, SQ_STEP_*): the samplers, the input
+staging of every forward, the verifier, both KV compactions and the 1-token draft forward read it there, the verifier
+writes the next one.  On a HIP device the sequence is captured once per (engines, growmap, sampling parameters) into a
+hipGraph and replayed per step; the host reads each step's 256-byte result record from a ring, one step late, through
+a copy stream -- the GPU never waits for the host inside or between steps.
+
+The static buffers (tokens, draft logits, noise, step block, staging buffers) belong to a StepState that outlives the
+per-prompt tree objects of the harness: a new tree adopts them (per-prompt constructor, outside the timed region).
+"""
+from __future__ import annotations
+
+import torch
+
+from ..Engine.Llama_modules import TreeContext
+from ..native import (SQ_RES_ACCEPT_LEN, SQ_RES_BONUS, SQ_RES_N_TREE, SQ_RES_TERMINAL, SQ_RESULT_INTS, SQ_RESULT_RING,
+                      SQ_STEP_ACTIVE, SQ_STEP_GT, SQ_STEP_INDEX, SQ_STEP_INTS, SQ_STEP_NEXT_GT, SQ_VERIFY_GATHER_FIRST)
+from ..ops import get_ops
+from .Tree import _content_key
+
+_STATES: dict = {}
+N_BONUS = 1024
+
+
+class _Fwd:
+    """Static inputs of one forward of fixed q_len (the analogue of a _GraphRunner's buffers)."""
+
+    def __init__(self, q_len, n_tree, bitmask, device):
+        self.q_len = q_len
+        self.ids = torch.zeros((1, q_len), dtype=torch.long, device=device)
+        self.pos = torch.zeros((1, q_len), dtype=torch.long, device=device)
+        self.sto = torch.zeros(q_len, dtype=torch.long, device=device)
+        self.ctx = torch.tensor([0, 1, q_len], dtype=torch.int32, device=device)
+        self.tree = TreeContext(q_slot0=0, gt=1, n_tree=n_tree, bitmask=bitmask, kv_len=q_len, ctx=self.ctx,
+                                contiguous_slots=True)
+
+
+class StepState:
+    """Static buffers + the captured step of one (draft engine, target engine, growmap, sampling parameters)."""
+
+    @staticmethod
+    def get(tree) -> "StepState":
+        key = (id(tree.draft_model_engine), id(tree.target_model_engine), _content_key(tree.grow_map), type(tree).__name__,
+               float(tree.temperature), float(tree.top_p), int(tree.max_length), int(tree.vocab_size), str(tree.device),
+               tree.commit_order)
+        st = _STATES.get(key)
+        if st is None:
+            st = _STATES[key] = StepState(tree)
+        return st
+
+    def __init__(self, tree):
+        dev, n, V, M = tree.device, tree.tree_size, tree.vocab_size, tree.max_length
+        self.device, self.n, self.V, self.M = dev, n, V, M
+        self.ops = get_ops()
+        self.stochastic = tree.stochastic
+        self.temperature, self.top_p = tree.temperature, tree.top_p
+        self.commit_order = tree.commit_order
+        self.gdev = tree.gdev
+        self.draft, self.target = tree.draft_model_engine, tree.target_model_engine
+        f16 = torch.float16
+        self.tokens = torch.zeros(M, dtype=torch.long, device=dev)
+        self.draft_logits = torch.zeros((n, V), dtype=f16, device=dev)
+        self.r = torch.zeros(M, dtype=f16, device=dev)
+        self.rand = torch.zeros((n, V), dtype=f16, device=dev) if self.stochastic else None
+        self.stats = torch.zeros(self.ops.stats_shape(n, V), dtype=torch.float32, device=dev) if self.stochastic else None
+        self.step = torch.zeros(SQ_STEP_INTS, dtype=torch.int32, device=dev)
+        self.bonus = torch.zeros(N_BONUS, dtype=torch.int32, device=dev)
+        self.result = torch.zeros(SQ_RESULT_INTS + n, dtype=torch.int32, device=dev)
+        self.ring = torch.zeros(SQ_RESULT_RING * SQ_RESULT_INTS, dtype=torch.int32, device=dev)
+        self.verify_ws = self.ops.verify_workspace(n, dev)
+        bm = self.gdev["bitmask"]
+        self.fwd_levels = [_Fwd(lv["total"], n, bm, dev) for lv in self.gdev["levels"]]
+        self.fwd_target = _Fwd(n, n, bm, dev)
+        self.fwd_one = _Fwd(1, n, bm, dev)
+        self.graph = None
+        self.cuda = str(dev).startswith("cuda")
+        if self.cuda:
+            self.copy_stream = torch.cuda.Stream(device=dev)
+            self.host_ring = torch.zeros((SQ_RESULT_RING, SQ_RESULT_INTS), dtype=torch.int32).pin_memory()
+            self.events = [None] * SQ_RESULT_RING
+
+    # ---- the launch sequence of one step --------------------------------------------------------------------
+    def body(self):
+        ops, g, n, T = self.ops, self.gdev, self.n, self.temperature
+        gt_dev = self.step[SQ_STEP_GT:SQ_STEP_GT + 1]
+        depth = g["depth32"]
+        dm, tm = self.draft.engine, self.target.engine
+        for lv, f in zip(g["levels"], self.fwd_levels):
+            first = lv["first_child"]
+            out = self.tokens[first - 1:]                 # + gt on the device: tokens[gt + first - 1 + out_off[r] + s]
+            if self.stochastic:
+                ops.sample_wor(self.draft_logits, self.rand, lv["row_ids"], lv["k"], T, out, branch=lv["branch"],
+                               out_off=lv["out_off"], out_base=gt_dev, stats=self.stats)
+            else:
+                ops.topk(self.draft_logits, lv["row_ids"], lv["k"], out, branch=lv["branch"], out_off=lv["out_off"],
+                         out_base=gt_dev)
+            ops.stage_tree_inputs(f.ids, f.pos, f.sto, f.ctx, self.tokens, depth, n, first - 1, first - 1 + lv["total"],
+                                  self.step)
+            logits = dm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None, tree=f.tree)
+            self._adopt_rows(logits[0], first, lv["total"])
+        f = self.fwd_target
+        ops.stage_tree_inputs(f.ids, f.pos, f.sto, f.ctx, self.tokens, depth, n, -1, n - 1, self.step)
+        target_logits = tm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None,
+                                     tree=f.tree)[0]
+        self.target_logits = target_logits
+        flags = SQ_VERIFY_GATHER_FIRST if self.commit_order == "lossless" else 0
+        if self.stochastic:
+            if self.top_p < 1.0:
+                ops.top_p_filter(target_logits, self.top_p, T)
+            ops.verify_stochastic(target_logits, self.draft_logits, self.tokens, self.r, g["child_off"], g["child_ids"], n, 0,
+                                  T, flags, self.verify_ws, self.result, step=self.step, bonus_table=self.bonus,
+                                  result_ring=self.ring)
+        else:
+            ops.verify_greedy(target_logits, self.tokens, g["child_off"], g["child_ids"], n, 0, self.verify_ws, self.result,
+                              step=self.step, result_ring=self.ring)
+        slots, count = self.result[SQ_RESULT_INTS:], self.result[SQ_RES_N_TREE:SQ_RES_N_TREE + 1]
+        for eng in (dm, tm):
+            kv = eng.kv_cache
+            ops.kv_compact(kv.k_cache, kv.v_cache, slots, count, g["max_depth"], 0, 0, dst_offset_dev=gt_dev)
+        f = self.fwd_one                                   # next root: the bonus token at slot new_gt - 1
+        ops.stage_tree_inputs(f.ids, f.pos, f.sto, f.ctx, self.tokens, depth, n, -1, 0, self.step, advance=True)
+        logits = dm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None, tree=f.tree)
+        self._adopt_rows(logits[0], 0, 1)
+
+    def _adopt_rows(self, rows, first, total):
+        """draft_logits[first:first+total] = the forward's last `total` rows (Tree/SpecTree.py:121,279), with the
+        per-part softmax statistics of those rows for the next sampler (one launch instead of a copy)."""
+        src = rows[-total:]
+        if self.stochastic:
+            self.ops.logits_stats(src, self.temperature, self.stats[first:first + total],
+                                  copy_dst=self.draft_logits[first:first + total])
+        else:
+            self.draft_logits[first:first + total].copy_(src)
+
+    # ---- capture --------------------------------------------------------------------------------------------
+    def _kv_marks(self):
+        return [(e.engine.kv_cache, e.engine.kv_cache.kv_offset, e.engine.kv_cache.dirty_end) for e in (self.draft, self.target)]
+
+    @torch.inference_mode()
+    def ensure_captured(self):
+        """Warm the sequence up (launch plans, weight images, workspaces) and capture it.  Runs real steps on scratch
+        state (gt = 1, empty caches): call before a prompt is prefilled; both KV caches are cleared afterwards."""
+        if self.graph is not None or not self.cuda:
+            return
+        from ..Engine.Engine import prime_graph_rng
+        prime_graph_rng(self.device)
+        marks = self._kv_marks()
+        self.step.zero_()
+        self.step[SQ_STEP_GT] = 1
+        self.step[SQ_STEP_ACTIVE] = 1
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.step[SQ_STEP_GT] = 1
+                self.body()
+            s.synchronize()
+        torch.cuda.current_stream().wait_stream(s)
+        self.step[SQ_STEP_GT] = 1
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.body()
+        self.graph = graph
+        for kv, off, dirty in marks:
+            kv.kv_offset, kv.dirty_end = off, dirty
+        self.draft.clear_kv(); self.target.clear_kv()
+        self.reset()
+
+    def reset(self):
+        self.tokens.zero_()
+        self.draft_logits.zero_()
+        self.step.zero_()
+        self.ring.zero_()
+
+    def launch(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.body()

@@ -55,6 +55,42 @@ extern "C" int sq_stage_inputs(int64_t* dst_ids, const int64_t* src_ids, int64_t
     return sq_check_launch();
 }
 
+// Device-driven staging of a tree forward (speculation step without host-side scalars): the q_len queries sit at slots
+// [gt + rel_slot0, gt + rel_slot0 + q_len) with gt read from the device step block; input ids come from the tree's token
+// buffer, storage ids are the slots, position ids follow Tree/SpecTree.py:61,264-270 (committed text: the slot itself;
+// tree node t at slot gt-1+t: depth[t] + gt - 1), the forward's context block becomes {q_slot0, gt, gt + rel_kv_len}.
+// advance != 0 first moves the step block to the next step (gt <- next_gt, index += 1): used by the forward that follows
+// the verification (the 1-token draft forward of prepare_for_next_iter, Tree/SpecTree.py:261-281).
+__global__ void stage_tree_inputs_kernel(int64_t* __restrict__ dst_ids, int64_t* __restrict__ dst_pos,
+                                         int64_t* __restrict__ dst_sto, int32_t* __restrict__ ctx,
+                                         const int64_t* __restrict__ tokens, const int32_t* __restrict__ depth, int n_tree,
+                                         int q_len, int rel_slot0, int rel_kv_len, int32_t* d_step, int advance) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = advance ? d_step[SQ_STEP_NEXT_GT] : d_step[SQ_STEP_GT];
+    const int q_slot0 = gt + rel_slot0;
+    if (i < q_len) {
+        const int slot = q_slot0 + i;
+        const int t = slot - (gt - 1);
+        dst_ids[i] = tokens[slot];
+        dst_sto[i] = slot;
+        dst_pos[i] = (t >= 0 && t < n_tree) ? (int64_t)depth[t] + gt - 1 : (int64_t)slot;
+    }
+    if (i < 3) ctx[i] = i == 0 ? q_slot0 : (i == 1 ? gt : gt + rel_kv_len);
+    if (advance && i == 0) {
+        d_step[SQ_STEP_GT] = gt;
+        d_step[SQ_STEP_INDEX] = d_step[SQ_STEP_INDEX] + 1;
+    }
+}
+extern "C" int sq_stage_tree_inputs(int64_t* dst_ids, int64_t* dst_pos, int64_t* dst_storage, int32_t* d_ctx,
+                                    const int64_t* tokens, const int32_t* d_depth, int n_tree, int q_len, int rel_slot0,
+                                    int rel_kv_len, int32_t* d_step, int advance, void* stream) {
+    if (!dst_ids || !dst_pos || !dst_storage || !d_ctx || !tokens || !d_depth || !d_step) return SQ_EINVAL;
+    if (q_len <= 0 || n_tree <= 0 || n_tree > SQ_MAX_TREE) return SQ_EINVAL;
+    hipLaunchKernelGGL(stage_tree_inputs_kernel, dim3((q_len + 127) / 128), dim3(128), 0, (hipStream_t)stream, dst_ids, dst_pos,
+                       dst_storage, d_ctx, tokens, d_depth, n_tree, q_len, rel_slot0, rel_kv_len, d_step, advance);
+    return sq_check_launch();
+}
+
 // ---- a1: bitmask from children CSR (host) ----------------------------------------------------
 extern "C" int sq_tree_bitmask_from_successors(const int32_t* child_off, const int32_t* child_ids,
                                                int n, uint64_t* out, int words) {
@@ -137,8 +173,9 @@ extern "C" int sq_kv_scatter_f16(void* k_layer, void* v_layer, const void* new_k
 // already consumed (SURVEY.md §7 "KV compaction aliasing").
 __global__ void __launch_bounds__(256) kv_compact_kernel(half_t* k_cache, half_t* v_cache, int m, int d,
                                                          const int32_t* slots, const int32_t* d_count, int max_count,
-                                                         int dst_offset, int zero_end) {
+                                                         int dst_offset, int zero_end, const int32_t* d_dst_offset) {
     half_t* tile = (blockIdx.y == 0 ? k_cache : v_cache) + (size_t)blockIdx.x * m * d;
+    if (d_dst_offset) dst_offset = *d_dst_offset;          // device-driven step: the ground-truth length lives on the device
     int count = d_count ? *d_count : max_count;
     if (count > max_count) count = max_count;
     if (count < 0) count = 0;
@@ -170,14 +207,16 @@ __global__ void __launch_bounds__(256) kv_compact_kernel(half_t* k_cache, half_t
 
 extern "C" int sq_kv_compact_f16(void* k_cache, void* v_cache, int n_layers, int h_kv, int m, int d,
                                  const int32_t* d_slots, const int32_t* d_count, int max_count, int dst_offset,
-                                 int zero_end, void* stream) {
+                                 int zero_end, const int32_t* d_dst_offset, void* stream) {
     if (!k_cache || !v_cache || n_layers <= 0 || h_kv <= 0 || m <= 0 || max_count < 0 || dst_offset < 0) return SQ_EINVAL;
     if (max_count > 0 && !d_slots) return SQ_EINVAL;
     if (d <= 0 || (d & 7) || d > 2048 || (256 % (d >> 3)) != 0) return SQ_EUNSUPPORTED;
     if (zero_end > m) return SQ_EINVAL;
-    if (max_count == 0 && zero_end <= dst_offset) return SQ_OK;
+    if (max_count == 0 && zero_end <= dst_offset && !d_dst_offset) return SQ_OK;
+    if (d_dst_offset && zero_end > 0) return SQ_EUNSUPPORTED;      // tail zeroing needs the host's view of the lengths
     hipLaunchKernelGGL(kv_compact_kernel, dim3(n_layers * h_kv, 2), dim3(256), 0, (hipStream_t)stream,
-                       (half_t*)k_cache, (half_t*)v_cache, m, d, d_slots, d_count, max_count, dst_offset, zero_end);
+                       (half_t*)k_cache, (half_t*)v_cache, m, d, d_slots, d_count, max_count, dst_offset, zero_end,
+                       d_dst_offset);
     return sq_check_launch();
 }
 

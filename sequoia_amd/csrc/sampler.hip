@@ -1,32 +1,214 @@
-// a2: draft-expansion samplers.  One 1024-thread workgroup per logits row; the whole row lives in
-// registers (EPT halves per thread, 16-byte coalesced loads), so the row is read from HBM exactly
-// once: softmax statistics, the Gumbel-style key log(u)/q and the top-k selection all run on the
-// register copy.  Rounding points follow the fp16 torch expression of the reference
-// (utils.py:10-18): y = h(x/T), q = h(exp(y-max)/sum), lu = h(log u), key = h(lu/q).
+// a2: draft-expansion samplers, every logits row split over `parts` workgroups (4096 elements each) so that a tree level
+// of 1-34 rows fills 8-272 compute units instead of 1-34:
+//   1. logits_stats_kernel   grid (rows, parts): y = h(x / T), per-part maximum m_p and s_p = sum exp(y - m_p)
+//                            (optionally also copies the row: in the speculation step this launch replaces the copy of
+//                            the draft forward's logits into the tree's draft_logits rows);
+//   2. sample_parts_kernel   grid (rows, parts): row statistics M = max m_p, z = sum_p s_p exp(m_p - M) (fixed order),
+//                            keys log(u) / q for the part's elements, local top-k (per-wave DPP arg-max rounds, then one
+//                            wave merges the 4 lists) -> candidate list of the part;
+//   3. sample_merge_kernel   one wave per row: merges parts x k candidates, writes the tokens.
+// The top-k sampler (greedy trees) runs 2 + 3 on the raw logits.  Rounding points follow the fp16 torch expression of the
+// reference (utils.py:10-18): y = h(x/T), q = h(exp(y-max)/sum), lu = h(log u), key = h(lu/q).
 //
-// Top-k = two-level tournament on 32-bit composites (ordered fp16 key << 16 | 0xffff - token id):
-// per-wave DPP arg-max rounds, then one wave merges the 16 candidate lists.  Ties resolve to the
-// lower token id.
+// Ordering = 32-bit composites (ordered fp16 key << 16 | 0xffff - token id): the maximum is the largest key and, inside
+// an exact tie, the lowest token id; vocabularies above 65536 use 64-bit composites (ordered key + 1 << 32 | ~id).
 #include "common.h"
 
-#define SAMP_THREADS 1024
-#define SAMP_WAVES (SAMP_THREADS / 64)
+#define PART_THREADS 256
+#define PART_WAVES (PART_THREADS / 64)
+#define PART_CH 2                                  // 16-byte chunks per thread
+#define PART_ELEMS (PART_THREADS * PART_CH * 8)    // 4096
+#define SAMP_MAX_PARTS 32                          // vocab <= 131072
 
-// element index of (chunk c, thread t, lane-element j) -- 16-byte chunks interleaved over threads
-__device__ __forceinline__ int elem_index(int c, int t, int j) { return (c * SAMP_THREADS + t) * 8 + j; }
+__host__ __device__ static inline int samp_parts(int vocab) { return (vocab + PART_ELEMS - 1) / PART_ELEMS; }
 
-template <int EPT, bool WOR>
-__global__ void __launch_bounds__(SAMP_THREADS)
-sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const half_t* __restrict__ rnd,
-                   int64_t ld_rand, const int32_t* __restrict__ row_ids, int vocab, int k, float temperature,
-                   int64_t* __restrict__ out, const int32_t* __restrict__ branch, const int32_t* __restrict__ out_off) {
-    constexpr int CH = EPT / 8;
-    __shared__ float s_f[SAMP_WAVES];
-    const int t = threadIdx.x;
-    const int r = blockIdx.x;
+// element index of (part p, chunk c, thread t, lane-element j) -- 16-byte chunks interleaved over threads
+__device__ __forceinline__ int part_elem(int p, int c, int t, int j) { return p * PART_ELEMS + (c * PART_THREADS + t) * 8 + j; }
+
+struct SampWs {
+    float* stats;       // [n_rows][parts][2]  (m_p, s_p) when the caller supplies none
+    void* cand;         // [n_rows][parts][k] composites (uint32 or uint64)
+};
+__host__ __device__ static inline size_t samp_stats_bytes(int n_rows, int vocab) {
+    return (((size_t)n_rows * samp_parts(vocab) * 2 * sizeof(float)) + 15) & ~(size_t)15;
+}
+extern "C" size_t sq_sample_workspace_bytes(int n_rows, int vocab, int k) {
+    if (n_rows <= 0 || vocab <= 0 || k <= 0) return 0;
+    return samp_stats_bytes(n_rows, vocab) + (size_t)n_rows * samp_parts(vocab) * k * sizeof(unsigned long long) + 64;
+}
+
+// ---- 1. per-part softmax statistics (+ optional row copy) ----------------------------------------------------------
+__global__ void __launch_bounds__(PART_THREADS)
+logits_stats_kernel(const half_t* __restrict__ logits, int64_t ld, const int32_t* __restrict__ row_ids, int vocab,
+                    float temperature, float* __restrict__ stats, int stats_by_source_row, half_t* __restrict__ copy_dst,
+                    int64_t ld_dst) {
+    __shared__ float s_f[PART_WAVES];
+    const int t = threadIdx.x, r = blockIdx.x, p = blockIdx.y, parts = gridDim.y;
+    const int64_t row = row_ids ? (int64_t)row_ids[r] : (int64_t)r;
+    const half_t* x = logits + row * ld;
+    float y[PART_CH * 8];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < PART_CH; ++c) {
+        const int e0 = part_elem(p, c, t, 0);
+        half8 v;
+        if (e0 < vocab) {
+            v = *(const half8*)(x + e0);
+            if (copy_dst) *(half8*)(copy_dst + (int64_t)r * ld_dst + e0) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float yy = (e0 < vocab) ? (float)(half_t)div_rn((float)v[j], temperature) : -INFINITY;
+            y[c * 8 + j] = yy;
+            lmax = fmaxf(lmax, yy);
+        }
+    }
+    const float m = block_max_f32<PART_WAVES>(lmax, s_f);
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < PART_CH * 8; ++i) lsum += exp_fast(y[i] - m);      // exp(-inf - m) = 0; m = -inf only for an all -inf part
+    const float s = block_sum_f32<PART_WAVES>(lsum, s_f);
+    if (t == 0) {
+        float* o = stats + ((size_t)(stats_by_source_row ? row : r) * parts + p) * 2;
+        o[0] = m;
+        o[1] = (m > -INFINITY) ? s : 0.f;
+    }
+}
+
+// row statistics from the per-part ones, identical in every consumer: M = max m_p, z = sum_p s_p exp(m_p - M) in part order
+__device__ __forceinline__ void combine_stats(const float* __restrict__ st, int parts, float& M, float& z) {
+    float mx = -INFINITY;
+    for (int q = 0; q < parts; ++q) mx = fmaxf(mx, st[q * 2]);
+    float acc = 0.f;
+    for (int q = 0; q < parts; ++q) {
+        const float mq = st[q * 2];
+        if (mq > -INFINITY) acc += st[q * 2 + 1] * exp_fast(mq - mx);
+    }
+    M = mx; z = acc;
+}
+
+// ---- 2. keys + local top-k of one part -----------------------------------------------------------------------------
+template <typename C> struct Comp;
+template <> struct Comp<uint32_t> {
+    static __device__ __forceinline__ uint32_t make(uint32_t ord, int e) { return (ord << 16) | (0xffffu - (uint32_t)e); }
+    static __device__ __forceinline__ int64_t id(uint32_t c) { return (int64_t)(0xffffu - (c & 0xffffu)); }
+    static __device__ __forceinline__ uint32_t wave_max(uint32_t v) { return wave_max_u32_dpp(v); }
+};
+template <> struct Comp<unsigned long long> {
+    static __device__ __forceinline__ unsigned long long make(uint32_t ord, int e) {
+        return ((unsigned long long)(ord + 1u) << 32) | (uint32_t)(0xffffffffu - (uint32_t)e);
+    }
+    static __device__ __forceinline__ int64_t id(unsigned long long c) { return (int64_t)(0xffffffffu - (uint32_t)(c & 0xffffffffu)); }
+    static __device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
+        // two 32-bit DPP maxima: the high words first, then the low words among the lanes that hold the maximum high word
+        const uint32_t hi = wave_max_u32_dpp((uint32_t)(v >> 32));
+        const uint32_t lo = wave_max_u32_dpp(((uint32_t)(v >> 32) == hi) ? (uint32_t)v : 0u);
+        return ((unsigned long long)hi << 32) | lo;
+    }
+};
+
+// k rounds of wave-wide arg-max over NPL composites per lane; round s stores the winner with `put(s, win)`.
+// Registers >= `used` (wave-uniform) hold nothing and are skipped with scalar branches.
+template <typename C, int NPL, typename Put>
+__device__ __forceinline__ void wave_topk(C (&comp)[NPL], int used, int n_out, int lane, Put put) {
+    C best = 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) if (i < used) best = comp[i] > best ? comp[i] : best;
+    for (int s = 0; s < n_out; ++s) {
+        const C win = Comp<C>::wave_max(best);            // wave-uniform
+        if (lane == 0) put(s, win);
+        if (win == 0) continue;
+        if (best == win) {                                // the owner (ids are unique) retires it and rescans its registers
+            best = 0;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                if (i < used) {
+                    if (comp[i] == win) comp[i] = 0;
+                    best = comp[i] > best ? comp[i] : best;
+                }
+            }
+        }
+    }
+}
+
+template <bool WOR, typename C>
+__global__ void __launch_bounds__(PART_THREADS)
+sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const half_t* __restrict__ rnd, int64_t ld_rand,
+                    const int32_t* __restrict__ row_ids, int vocab, int k, float temperature,
+                    const float* __restrict__ stats, int stats_by_source_row, const int32_t* __restrict__ branch,
+                    C* __restrict__ cand) {
+    constexpr int EPT = PART_CH * 8;
+    __shared__ C s_cand[PART_WAVES * SQ_MAX_TOPK];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = blockIdx.x, p = blockIdx.y, parts = gridDim.y;
+    int n_out = k;
+    if (branch) { n_out = branch[r]; if (n_out > k) n_out = k; }
+    if (n_out <= 0) return;                                // uniform per block
     const int64_t row = row_ids ? (int64_t)row_ids[r] : (int64_t)r;
     const half_t* x = logits + row * ld_logits;
 
+    C comp[EPT];
+    if (WOR) {
+        const half_t* u = rnd + row * ld_rand;
+        half8 xv[PART_CH], uv[PART_CH];
+#pragma unroll
+        for (int c = 0; c < PART_CH; ++c) {
+            const int e0 = part_elem(p, c, t, 0);
+            if (e0 < vocab) { xv[c] = *(const half8*)(x + e0); uv[c] = *(const half8*)(u + e0); }
+        }
+        float M, z;
+        combine_stats(stats + (size_t)(stats_by_source_row ? row : r) * parts * 2, parts, M, z);
+#pragma unroll
+        for (int c = 0; c < PART_CH; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = part_elem(p, c, t, j);
+                C v = 0;
+                if (part_elem(p, c, t, 0) < vocab) {            // vocab % 8 == 0: chunks are in or out as a whole
+                    const float yy = (float)(half_t)div_rn((float)xv[c][j], temperature);
+                    const half_t q = (half_t)div_rn(exp_fast(yy - M), z);
+                    const half_t lu = (half_t)log_fast((float)uv[c][j]);
+                    // lu / 0 = -inf (lu < 0 always: u < 1); otherwise the correctly rounded quotient
+                    const half_t key = (q == (half_t)0.0f) ? (half_t)(-INFINITY) : (half_t)div_rn((float)lu, (float)q);
+                    v = Comp<C>::make(f16_to_ordered(key), e);
+                }
+                comp[c * 8 + j] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < PART_CH; ++c) {
+            const int e0 = part_elem(p, c, t, 0);
+            half8 v;
+            if (e0 < vocab) v = *(const half8*)(x + e0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) comp[c * 8 + j] = (e0 < vocab) ? Comp<C>::make(f16_to_ordered(v[j]), e0 + j) : (C)0;
+        }
+    }
+    // level 1: every wave extracts its own top-n_out (no barriers); level 2: wave 0 merges the 4 lists
+    wave_topk<C, EPT>(comp, EPT, n_out, lane, [&](int s, C win) { s_cand[wave * SQ_MAX_TOPK + s] = win; });
+    __syncthreads();
+    if (wave == 0) {
+        constexpr int CPL = PART_WAVES * SQ_MAX_TOPK / 64;     // 8
+        C c[CPL];
+        const int total = PART_WAVES * n_out;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int idx = j * 64 + lane;                     // (wave w, rank s) = (idx / n_out, idx % n_out)
+            c[j] = idx < total ? s_cand[(idx / n_out) * SQ_MAX_TOPK + (idx % n_out)] : (C)0;
+        }
+        C* dst = cand + ((size_t)r * parts + p) * k;
+        wave_topk<C, CPL>(c, (total + 63) >> 6, n_out, lane, [&](int s, C win) { dst[s] = win; });
+    }
+}
+
+// ---- 3. merge the parts' candidate lists, one wave per row ----------------------------------------------------------
+template <typename C, int CPL>
+__global__ void __launch_bounds__(64)
+sample_merge_kernel(const C* __restrict__ cand, int parts, int k, int64_t* __restrict__ out,
+                    const int32_t* __restrict__ branch, const int32_t* __restrict__ out_off,
+                    const int32_t* __restrict__ out_base) {
+    const int r = blockIdx.x, lane = threadIdx.x;            // 64 * CPL >= parts * k candidates
     int n_out = k;
     int64_t* dst = out + (int64_t)r * k;
     if (branch) {
@@ -34,222 +216,99 @@ sample_rows_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const h
         if (n_out > k) n_out = k;
         dst = out + out_off[r];
     }
-    if (n_out <= 0) return;   // uniform per block
-
-    half_t key[EPT];          // fp16 keys (WOR) or raw logits (top-k)
-    if (WOR) {
-        float y[EPT];
-        float lmax = -INFINITY;
-        // the noise row is fetched together with the logits row: one HBM latency instead of two
-        const half_t* u = rnd + row * ld_rand;
-        half8 uv[CH];
+    if (out_base) dst += *out_base;
+    if (n_out <= 0) return;
+    const C* src = cand + (size_t)r * parts * k;
+    const int total = parts * n_out;
+    C c[CPL];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int e0 = elem_index(c, t, 0);
-            if (e0 < vocab) uv[c] = *(const half8*)(u + e0);
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int e0 = elem_index(c, t, 0);
-            half8 v;
-            if (e0 < vocab) v = *(const half8*)(x + e0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float yy = -INFINITY;
-                if (e0 + j < vocab) yy = (float)(half_t)div_rn((float)v[j], temperature);
-                y[c * 8 + j] = yy;
-                lmax = fmaxf(lmax, yy);
-            }
-        }
-        const float mx = block_max_f32<SAMP_WAVES>(lmax, s_f);
-        float lsum = 0.f;
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            y[i] = exp_fast(y[i] - mx);          // exp(-inf) = 0 for padding
-            lsum += y[i];
-        }
-        const float z = block_sum_f32<SAMP_WAVES>(lsum, s_f);
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const half_t q = (half_t)div_rn(y[c * 8 + j], z);
-                const half_t lu = (half_t)log_fast((float)uv[c][j]);
-                // lu / 0 = -inf (lu < 0 always: u < 1); otherwise the correctly rounded quotient
-                key[c * 8 + j] = (q == (half_t)0.0f) ? (half_t)(-INFINITY) : (half_t)div_rn((float)lu, (float)q);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int e0 = elem_index(c, t, 0);
-            half8 v;
-            if (e0 < vocab) v = *(const half8*)(x + e0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) key[c * 8 + j] = v[j];
-        }
+    for (int j = 0; j < CPL; ++j) {
+        const int idx = j * 64 + lane;
+        c[j] = idx < total ? src[(size_t)(idx / n_out) * k + (idx % n_out)] : (C)0;
     }
-
-    // ---- top-k: two-level tournament -----------------------------------------------------------
-    // composite = ordered fp16 key << 16 | (0xffff - token id): the maximum is the largest key and,
-    // inside an exact tie, the lowest token id.  (Token ids need 16 bits: vocab <= 65536; wider
-    // vocabularies take the 64-bit path below.)  Level 1: every wave extracts its own top-n_out with
-    // DPP arg-max rounds (no barriers); level 2: wave 0 merges the 16 x n_out candidates.
-    if (vocab <= 65536) {
-        __shared__ uint32_t s_cand[SAMP_WAVES * SQ_MAX_TOPK];
-        const int lane = t & 63, wave = t >> 6;
-        // composites are built once; a retired element becomes 0 and each round is one
-        // compare-select-max sweep over the thread's registers
-        uint32_t comp[EPT];
-        uint32_t gmax[CH];                               // running maximum of every 8-element chunk
-        uint32_t best = 0u;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            uint32_t m = 0u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = elem_index(c, t, j);
-                const uint32_t v = (e < vocab) ? ((f16_to_ordered(key[c * 8 + j]) << 16) | (0xffffu - (uint32_t)e)) : 0u;
-                comp[c * 8 + j] = v;
-                m = v > m ? v : m;
-            }
-            gmax[c] = m;
-            best = m > best ? m : best;
-        }
-        for (int s = 0; s < n_out; ++s) {
-            const uint32_t win = wave_max_u32_dpp(best);  // wave-uniform (SGPR)
-            if (lane == 0) s_cand[wave * SQ_MAX_TOPK + s] = win;
-            if (win == 0u) continue;
-            // the winner's chunk follows from its token id: only that chunk is rescanned (a scalar branch per
-            // chunk, the id is wave-uniform), and only in the lane that owns it
-            const int wc = (int)(((0xffffu - (win & 0xffffu)) >> 3) / SAMP_THREADS);
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                if (c == wc) {
-                    uint32_t m = 0u;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t v = (comp[c * 8 + j] == win) ? 0u : comp[c * 8 + j];
-                        comp[c * 8 + j] = v;
-                        m = v > m ? v : m;
-                    }
-                    gmax[c] = m;
-                }
-            }
-            best = 0u;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) best = gmax[c] > best ? gmax[c] : best;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            // 16 sorted lists of n_out candidates; lane l owns candidates l, l+64, ...
-            constexpr int CPL = SAMP_WAVES * SQ_MAX_TOPK / 64;     // 32
-            uint32_t c[CPL];
-            const int total = SAMP_WAVES * n_out;
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-                const int idx = j * 64 + lane;                     // (wave w, rank s) = (idx / n_out, idx % n_out)
-                c[j] = idx < total ? s_cand[(idx / n_out) * SQ_MAX_TOPK + (idx % n_out)] : 0u;
-            }
-            uint32_t lb = 0u;
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) lb = c[j] > lb ? c[j] : lb;
-            const int used = (total + 63) >> 6;            // candidate registers that hold anything (5 of 32 for k = 19)
-            for (int s = 0; s < n_out; ++s) {
-                const uint32_t win = wave_max_u32_dpp(lb);
-                if (lane == 0) dst[s] = (win == 0u) ? 0 : (int64_t)(0xffffu - (win & 0xffffu));
-                if (win == lb && win != 0u) {
-                    lb = 0u;
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        if (j < used) {
-                            if (c[j] == win) c[j] = 0u;
-                            lb = c[j] > lb ? c[j] : lb;
-                        }
-                    }
-                }
-            }
-        }
-        return;
-    }
-    // ---- wide-vocabulary path: k rounds of block-wide arg-max on 64-bit composites ------------------
-    unsigned long long best;
-    auto local_best = [&](uint32_t removed_lo, uint32_t removed_hi, uint32_t removed_2, uint32_t removed_3) {
-        unsigned long long b = 0ull;
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const uint32_t word = i < 32 ? removed_lo : (i < 64 ? removed_hi : (i < 96 ? removed_2 : removed_3));
-            const bool gone = (word >> (i & 31)) & 1u;
-            const int e = elem_index(i >> 3, t, i & 7);
-            if (!gone && e < vocab) {
-                const unsigned long long comp =
-                    ((unsigned long long)(f16_to_ordered(key[i]) + 1u) << 32) | (uint32_t)(0xffffffffu - (uint32_t)e);
-                b = comp > b ? comp : b;
-            }
-        }
-        return b;
-    };
-    uint32_t rm0 = 0, rm1 = 0, rm2 = 0, rm3 = 0;
-    best = local_best(rm0, rm1, rm2, rm3);
-    __shared__ unsigned long long s_b[SAMP_WAVES];
-    for (int s = 0; s < n_out; ++s) {
-        const unsigned long long win = block_max_u64<SAMP_WAVES>(best, s_b);
-        const uint32_t e = 0xffffffffu - (uint32_t)(win & 0xffffffffu);
-        if (t == 0) dst[s] = (win == 0ull) ? 0 : (int64_t)e;
-        if (win == best && win != 0ull) {
-            const int c = (int)(e >> 3) / SAMP_THREADS;
-            const int i = c * 8 + (int)(e & 7);
-            if (i < 32) rm0 |= 1u << i;
-            else if (i < 64) rm1 |= 1u << (i - 32);
-            else if (i < 96) rm2 |= 1u << (i - 64);
-            else rm3 |= 1u << (i - 96);
-            best = local_best(rm0, rm1, rm2, rm3);
-        }
-    }
+    wave_topk<C, CPL>(c, (total + 63) >> 6, n_out, lane, [&](int s, C win) { dst[s] = (win == 0) ? 0 : Comp<C>::id(win); });
 }
 
-template <bool WOR>
-static int launch_rows(const void* logits, int64_t ld_logits, const void* rnd, int64_t ld_rand,
-                       const int32_t* row_ids, int n_rows, int vocab, int k, float temperature, int64_t* out,
-                       const int32_t* branch, const int32_t* out_off, hipStream_t st) {
-    dim3 g(n_rows), b(SAMP_THREADS);
-#define SQ_LAUNCH(EPT)                                                                                         \
-    hipLaunchKernelGGL((sample_rows_kernel<EPT, WOR>), g, b, 0, st, (const half_t*)logits, ld_logits,            \
-                       (const half_t*)rnd, ld_rand, row_ids, vocab, k, temperature, out, branch, out_off)
-    if (vocab <= 8 * SAMP_THREADS) SQ_LAUNCH(8);
-    else if (vocab <= 32 * SAMP_THREADS) SQ_LAUNCH(32);
-    else if (vocab <= 128 * SAMP_THREADS) SQ_LAUNCH(128);
-    else return SQ_EUNSUPPORTED;
-#undef SQ_LAUNCH
+// ---- host side ---------------------------------------------------------------------------------------------------
+static int check_rows(const void* logits, int64_t ld, int n_rows, int vocab, int k, const int64_t* out,
+                      const int32_t* branch, const int32_t* out_off, const void* workspace) {
+    if (!logits || !out || !workspace || n_rows < 0 || vocab <= 0 || k <= 0 || ld < vocab) return SQ_EINVAL;
+    if ((branch == nullptr) != (out_off == nullptr)) return SQ_EINVAL;
+    if (k > SQ_MAX_TOPK || k > vocab) return SQ_EUNSUPPORTED;
+    if ((vocab & 7) || (ld & 7) || ((uintptr_t)logits & 15) || samp_parts(vocab) > SAMP_MAX_PARTS) return SQ_EUNSUPPORTED;
+    return SQ_OK;
+}
+
+template <bool WOR, typename C>
+static int launch_sampler(const void* logits, int64_t ld_logits, const void* rnd, int64_t ld_rand, const int32_t* row_ids,
+                          int n_rows, int vocab, int k, float temperature, int64_t* out, const int32_t* branch,
+                          const int32_t* out_off, const int32_t* out_base, const float* stats, int by_source_row,
+                          void* workspace, hipStream_t st) {
+    const int parts = samp_parts(vocab);
+    C* cand = (C*)((char*)workspace + samp_stats_bytes(n_rows, vocab));
+    hipLaunchKernelGGL((sample_parts_kernel<WOR, C>), dim3(n_rows, parts), dim3(PART_THREADS), 0, st, (const half_t*)logits,
+                       ld_logits, (const half_t*)rnd, ld_rand, row_ids, vocab, k, temperature, stats, by_source_row, branch,
+                       cand);
+    int rc = sq_check_launch();
+    if (rc != SQ_OK) return rc;
+#define SQ_MERGE(CPL) hipLaunchKernelGGL((sample_merge_kernel<C, CPL>), dim3(n_rows), dim3(64), 0, st, (const C*)cand, parts, \
+                                         k, out, branch, out_off, out_base)
+    if (parts * k <= 64 * 4) SQ_MERGE(4);
+    else if (parts * k <= 64 * 16) SQ_MERGE(16);
+    else SQ_MERGE(SAMP_MAX_PARTS * SQ_MAX_TOPK / 64);
+#undef SQ_MERGE
     return sq_check_launch();
 }
 
-static int check_rows(const void* logits, int64_t ld, int n_rows, int vocab, int k, const int64_t* out,
-                      const int32_t* branch, const int32_t* out_off) {
-    if (!logits || !out || n_rows < 0 || vocab <= 0 || k <= 0 || ld < vocab) return SQ_EINVAL;
-    if ((branch == nullptr) != (out_off == nullptr)) return SQ_EINVAL;
-    if (k > SQ_MAX_TOPK || k > vocab) return SQ_EUNSUPPORTED;
-    if ((vocab & 7) || (ld & 7) || ((uintptr_t)logits & 15)) return SQ_EUNSUPPORTED;
-    return SQ_OK;
+extern "C" int sq_logits_stats_f16(const void* logits, int64_t ld, const int32_t* d_row_ids, int n_rows, int vocab,
+                                   float temperature, float* d_stats, int stats_by_source_row, void* copy_dst,
+                                   int64_t ld_dst, void* stream) {
+    if (!logits || !d_stats || n_rows < 0 || vocab <= 0 || ld < vocab || !(temperature > 0.f)) return SQ_EINVAL;
+    if ((vocab & 7) || (ld & 7) || ((uintptr_t)logits & 15) || samp_parts(vocab) > SAMP_MAX_PARTS) return SQ_EUNSUPPORTED;
+    if (copy_dst && (ld_dst < vocab || (ld_dst & 7) || ((uintptr_t)copy_dst & 15))) return SQ_EINVAL;
+    if (n_rows == 0) return SQ_OK;
+    hipLaunchKernelGGL(logits_stats_kernel, dim3(n_rows, samp_parts(vocab)), dim3(PART_THREADS), 0, (hipStream_t)stream,
+                       (const half_t*)logits, ld, d_row_ids, vocab, temperature, d_stats, stats_by_source_row,
+                       (half_t*)copy_dst, ld_dst);
+    return sq_check_launch();
 }
 
 extern "C" int sq_sample_wor_f16(const void* logits, int64_t ld_logits, const void* rnd, int64_t ld_rand,
                                  const int32_t* d_row_ids, int n_rows, int vocab, int k, float temperature,
-                                 int64_t* out, const int32_t* d_branch, const int32_t* d_out_off, void* stream) {
-    int rc = check_rows(logits, ld_logits, n_rows, vocab, k, out, d_branch, d_out_off);
+                                 int64_t* out, const int32_t* d_branch, const int32_t* d_out_off,
+                                 const int32_t* d_out_base, const float* d_stats, void* workspace, void* stream) {
+    int rc = check_rows(logits, ld_logits, n_rows, vocab, k, out, d_branch, d_out_off, workspace);
     if (rc != SQ_OK) return rc;
     if (!rnd || ld_rand < vocab || (ld_rand & 7) || ((uintptr_t)rnd & 15)) return SQ_EINVAL;
     if (!(temperature > 0.f)) return SQ_EINVAL;
     if (n_rows == 0) return SQ_OK;
-    return launch_rows<true>(logits, ld_logits, rnd, ld_rand, d_row_ids, n_rows, vocab, k, temperature, out, d_branch,
-                             d_out_off, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const float* stats = d_stats;
+    int by_source = 1;
+    if (!stats) {                       // statistics of exactly these rows, indexed by launch row
+        rc = sq_logits_stats_f16(logits, ld_logits, d_row_ids, n_rows, vocab, temperature, (float*)workspace, 0, nullptr, 0,
+                                 stream);
+        if (rc != SQ_OK) return rc;
+        stats = (const float*)workspace;
+        by_source = 0;
+    }
+    if (vocab <= 65536)
+        return launch_sampler<true, uint32_t>(logits, ld_logits, rnd, ld_rand, d_row_ids, n_rows, vocab, k, temperature, out,
+                                              d_branch, d_out_off, d_out_base, stats, by_source, workspace, st);
+    return launch_sampler<true, unsigned long long>(logits, ld_logits, rnd, ld_rand, d_row_ids, n_rows, vocab, k, temperature,
+                                                    out, d_branch, d_out_off, d_out_base, stats, by_source, workspace, st);
 }
 
 extern "C" int sq_topk_f16(const void* logits, int64_t ld_logits, const int32_t* d_row_ids, int n_rows, int vocab,
-                           int k, int64_t* out, const int32_t* d_branch, const int32_t* d_out_off, void* stream) {
-    int rc = check_rows(logits, ld_logits, n_rows, vocab, k, out, d_branch, d_out_off);
+                           int k, int64_t* out, const int32_t* d_branch, const int32_t* d_out_off,
+                           const int32_t* d_out_base, void* workspace, void* stream) {
+    int rc = check_rows(logits, ld_logits, n_rows, vocab, k, out, d_branch, d_out_off, workspace);
     if (rc != SQ_OK) return rc;
     if (n_rows == 0) return SQ_OK;
-    return launch_rows<false>(logits, ld_logits, nullptr, 0, d_row_ids, n_rows, vocab, k, 1.0f, out, d_branch, d_out_off,
-                              (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (vocab <= 65536)
+        return launch_sampler<false, uint32_t>(logits, ld_logits, nullptr, 0, d_row_ids, n_rows, vocab, k, 1.0f, out, d_branch,
+                                               d_out_off, d_out_base, nullptr, 0, workspace, st);
+    return launch_sampler<false, unsigned long long>(logits, ld_logits, nullptr, 0, d_row_ids, n_rows, vocab, k, 1.0f, out,
+                                                     d_branch, d_out_off, d_out_base, nullptr, 0, workspace, st);
 }

@@ -12,6 +12,8 @@
 // 2^-24 grid, so they are independent of reduction order.
 #include "common.h"
 
+// vocab is a multiple of 8 (checked by every entry point): a 16-byte chunk is inside the row or outside it as a whole,
+// so bounds are tested per chunk (e0 < vocab), never per element
 #define VER_THREADS 1024
 #define VER_WAVES (VER_THREADS / 64)
 
@@ -50,39 +52,69 @@ __device__ __forceinline__ half_t grid_sum_to_f16(unsigned long long total) {
     return (half_t)ldexpf((float)(uint32_t)q, shift - 24);
 }
 
-// softmax(x / T) with the reference's rounding: returns h(exp(y - max) / sum) per element
+// Correctly rounded a / b for a wave-uniform divisor: the refined reciprocal is computed once, every quotient costs one
+// multiply and two fused multiply-adds (same result as div_rn for finite a).
+struct RcpDiv {
+    float b, r;
+    __device__ __forceinline__ explicit RcpDiv(float b_) : b(b_) {
+        const float r0 = __builtin_amdgcn_rcpf(b_);
+        r = __builtin_fmaf(__builtin_fmaf(-b_, r0, 1.0f), r0, r0);
+    }
+    __device__ __forceinline__ float operator()(float a) const {     // a finite
+        const float q0 = a * r;
+        float q = __builtin_fmaf(__builtin_fmaf(-q0, b, a), r, q0);
+        // The quotient must exist as an fp32 value: callers round it to fp16 next, and the reference's result is that
+        // DOUBLE rounding (fp32 division, then the cast).  Without the barrier the compiler folds the cast into the
+        // last fma (v_fma_mixlo_f16: one rounding of the exact fma result), which differs near fp16 ties.
+        asm volatile("" : "+v"(q));
+        return q;
+    }
+};
+
+// softmax(x / T) with the reference's rounding: returns h(exp(y - max) / sum) per element (y = h(x / T)).  The
+// exponentials stay in registers between the sum pass and the normalisation (the array is dead afterwards).
+__device__ __forceinline__ half8 neg_inf8() {
+    const half_t n = (half_t)(-INFINITY);
+    return half8{n, n, n, n, n, n, n, n};
+}
+
+// fp16 register arrays are held as explicit pairs (one VGPR per two elements); element i of a pair array:
+#define H2(arr, i) arr[(i) >> 1][(i) & 1]
+
 template <int EPT>
 __device__ __forceinline__ void row_softmax_f16(const half_t* __restrict__ x, int vocab, float temperature, int t,
-                                                half_t (&p)[EPT], float* s_f) {
-    // p first holds y = h(x / T) (fp16), then the probabilities; the exponential is evaluated twice
-    // (sum pass, normalise pass) rather than parked in EPT fp32 registers.
+                                                half2v (&p)[EPT / 2], float* s_f) {
+    float e[EPT];
+    const RcpDiv div_t(temperature);
     float lmax = -INFINITY;
 #pragma unroll
     for (int c = 0; c < EPT / 8; ++c) {
         const int e0 = v_elem(c, t, 0);
-        half8 v;
+        half8 v = neg_inf8();                                   // chunks past the row end read as -inf (branch-free below)
         if (e0 < vocab) v = *(const half8*)(x + e0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const half_t yy = (e0 + j < vocab) ? (half_t)div_rn((float)v[j], temperature) : (half_t)(-INFINITY);
-            p[c * 8 + j] = yy;
-            lmax = fmaxf(lmax, (float)yy);
+            const float xv = (float)v[j];
+            const float yy = (float)(half_t)((__builtin_fabsf(xv) < INFINITY) ? div_t(xv) : xv);   // +-inf / NaN pass through (T > 0)
+            e[c * 8 + j] = yy;
+            lmax = fmaxf(lmax, yy);
         }
     }
     const float mx = block_max_f32<VER_WAVES>(lmax, s_f);
     float lsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) lsum += exp_fast((float)p[i] - mx);
+    for (int i = 0; i < EPT; ++i) { e[i] = exp_fast(e[i] - mx); lsum += e[i]; }
     const float z = block_sum_f32<VER_WAVES>(lsum, s_f);
+    const RcpDiv div_z(z);
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) p[i] = (half_t)div_rn(exp_fast((float)p[i] - mx), z);
+    for (int i = 0; i < EPT; ++i) H2(p, i) = (half_t)div_z(e[i]);
 }
 
 // Exact inverse CDF of a (possibly unnormalised) fp16 distribution held EPT elements per thread: the token whose
 // cumulative mass interval, in element-index order (chunk, thread, j) and in exact integer arithmetic on the 2^-24
 // grid, contains u24 / 2^24 of the total.  Returns -1 for an all-zero distribution.  Block-uniform result.
 template <int EPT>
-__device__ __forceinline__ int block_inverse_cdf(const half_t (&p)[EPT], int vocab, int t, uint32_t u24) {
+__device__ __forceinline__ int block_inverse_cdf(const half2v (&p)[EPT / 2], int vocab, int t, uint32_t u24) {
     constexpr int CH = EPT / 8;
     __shared__ unsigned long long s_ct[VER_WAVES][EPT / 8];
     __shared__ unsigned long long s_scan[VER_WAVES];
@@ -94,7 +126,7 @@ __device__ __forceinline__ int block_inverse_cdf(const half_t (&p)[EPT], int voc
         uint32_t sv = 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (v_elem(c, t, j) < vocab) sv += (uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+            if (v_elem(c, t, 0) < vocab) sv += (uint32_t)((float)H2(p, c * 8 + j) * 16777216.0f);
         csum[c] = sv;
         const unsigned long long wsum = wave_sum_u32_wide_dpp(sv);
         if ((t & 63) == 0) s_ct[t >> 6][c] = wsum;
@@ -146,7 +178,7 @@ __device__ __forceinline__ int block_inverse_cdf(const half_t (&p)[EPT], int voc
             if (c == cstar) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    acc += (unsigned long long)(uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+                    acc += (unsigned long long)(uint32_t)((float)H2(p, c * 8 + j) * 16777216.0f);
                     if (pick < 0 && acc > thr) pick = v_elem(c, t, j);
                 }
             }
@@ -179,14 +211,24 @@ __device__ __forceinline__ Red3 block_red3(uint32_t isum32, float fmx, float fsu
     return r;
 }
 
+// Device-resident step state read by the device-driven speculation step (include/sequoia_hip.h, SQ_STEP_*).
+__device__ __forceinline__ int step_gt(const int32_t* d_step, int gt) { return d_step ? d_step[SQ_STEP_GT] : gt; }
+
 // REPLACE = SpecInfer's rule (Tree/SpecInferTree.py:141-164): children were drawn WITH replacement, so a rejected
 // token stays in q (no masking, no renormalisation of q) and the test is p >= r q.
+//
+// Per thread: the target distribution p (fp16; after a rejection the UNNORMALISED residual d = relu(p - q), its
+// normaliser `sf` is applied on the fly by the next pass), the draft row y = h(x / T) (fp16, rejected tokens -inf) and
+// its exponentials e = exp(y - mx) (fp32, computed once per maximum).  One rejection = one pass over the registers
+// (p <- h(d / sf); q <- h(e / z); d <- relu(h(p - q)); exact integer sum of d; fresh sum / maximum of the draft without the
+// rejected token) and one block reduction.
 template <int EPT, bool REPLACE>
 __global__ void __launch_bounds__(VER_THREADS)
 verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __restrict__ draft_logits,
                     const int64_t* __restrict__ tokens, const half_t* __restrict__ r16,
                     const int32_t* __restrict__ child_off, const int32_t* __restrict__ child_ids, int n_tree,
-                    int vocab, int gt, float temperature, uint32_t u24, void* ws_raw) {
+                    int vocab, int gt_arg, float temperature, uint32_t u24_arg, void* ws_raw,
+                    const int32_t* __restrict__ d_step, const uint32_t* __restrict__ d_bonus, int n_bonus) {
     constexpr int CH = EPT / 8;
     __shared__ float s_f[VER_WAVES];
     __shared__ float s_m[VER_WAVES];
@@ -196,35 +238,45 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
     const int t = threadIdx.x;
     const int node = blockIdx.x;
     const VerifyWs ws = ws_layout(ws_raw, n_tree);
+    const int gt = step_gt(d_step, gt_arg);
+    const uint32_t u24 = (d_step && d_bonus) ? (d_bonus[(uint32_t)d_step[SQ_STEP_INDEX] % (uint32_t)n_bonus] & 0xffffffu) : u24_arg;
 
-    half_t p[EPT];
+    half2v p[EPT / 2];
     row_softmax_f16<EPT>(target_logits + (size_t)node * vocab, vocab, temperature, t, p, s_f);
 
     const int c0 = child_off[node], nc = child_off[node + 1] - c0;
     int accepted = -1, nrej = 0, nan_flag = 0;
+    float sf = 1.0f;                      // normaliser of p: 1 = p holds probabilities, else p holds relu(p - q) and sf its sum
+    bool scaled = false;
     if (nc > 0) {
-        // draft side: yd = h(draft_logits / T) (rejected tokens become -inf), q = h(exp(yd - mx) / z).
-        // Only p and yd (fp16, 16 VGPRs each) stay live across the child loop; exponentials are
-        // recomputed per pass (7 instructions) instead of being kept in 32 more registers.
-        half_t yd[EPT];
+        // draft side: e = exp(y - mx) with y = h(x / T); a rejected token gets e = 0 and its bit in `masked` (the row is
+        // re-read from L2 only when the maximum itself is rejected and the exponentials have to be rebased)
+        float e[EPT];
+        uint32_t masked = 0u;
         const half_t* xd = draft_logits + (size_t)node * vocab;
-        float lmax = -INFINITY;
+        const RcpDiv div_t(temperature);
+        auto load_y = [&](float (&y)[EPT]) {
+            float lmax = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int e0 = v_elem(c, t, 0);
-            half8 v;
-            if (e0 < vocab) v = *(const half8*)(xd + e0);
+            for (int c = 0; c < CH; ++c) {
+                const int e0 = v_elem(c, t, 0);
+                half8 v = neg_inf8();
+                if (e0 < vocab) v = *(const half8*)(xd + e0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const half_t yy = (e0 + j < vocab) ? (half_t)div_rn((float)v[j], temperature) : (half_t)(-INFINITY);
-                yd[c * 8 + j] = yy;
-                lmax = fmaxf(lmax, (float)yy);
+                for (int j = 0; j < 8; ++j) {
+                    const float xv = (float)v[j];
+                    float yy = (float)(half_t)((__builtin_fabsf(xv) < INFINITY) ? div_t(xv) : xv);   // +-inf / NaN pass through (T > 0)
+                    yy = ((masked >> (c * 8 + j)) & 1u) ? -INFINITY : yy;
+                    y[c * 8 + j] = yy;
+                    lmax = fmaxf(lmax, yy);
+                }
             }
-        }
-        float mx = block_max_f32<VER_WAVES>(lmax, s_f);
+            return lmax;
+        };
+        float mx = block_max_f32<VER_WAVES>(load_y(e), s_f);
         float lsum = 0.f;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) lsum += exp_fast((float)yd[i] - mx);
+        for (int i = 0; i < EPT; ++i) { e[i] = exp_fast(e[i] - mx); lsum += e[i]; }
         float z = block_sum_f32<VER_WAVES>(lsum, s_f);
 
         for (int jc = 0; jc < nc; ++jc) {
@@ -236,51 +288,57 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             // a scalar index compare instead of 32 per-thread element ids held in registers
             const bool mine = t == ((tok >> 3) & (VER_THREADS - 1));
             const int tok_local = ((tok >> 3) / VER_THREADS) * 8 + (tok & 7);
+            const RcpDiv div_sf(sf), div_z(z);
             // broadcast e[tok], p[tok] from the owning thread
 #pragma unroll
             for (int i = 0; i < EPT; ++i)
-                if (mine && i == tok_local) { s_tok[0] = exp_fast((float)yd[i] - mx); s_tok[1] = (float)p[i]; }
+                if (mine && i == tok_local) {
+                    s_tok[0] = e[i];
+                    s_tok[1] = scaled ? (float)(half_t)div_sf((float)H2(p, i)) : (float)H2(p, i);
+                }
             __syncthreads();
-            const half_t q_tok = (half_t)div_rn(s_tok[0], z);
+            const float e_tok = s_tok[0];
+            const half_t q_tok = (half_t)div_z(e_tok);
             const half_t p_tok = (half_t)s_tok[1];
             const half_t rq = (half_t)((float)rr * (float)q_tok);
             const bool ok = (tok >= 0 && tok < vocab) && (REPLACE ? (p_tok >= rq) : (p_tok > rq));   // Tree/SpecTree.py:152 (strict)
             if (ok) { accepted = child; break; }
             // reject: p <- relu(p - q) / sum(relu(p - q));  draft_logits[tok] <- -65504 (=> q[tok] = 0)
             uint32_t lint = 0u;
-            float nmax = -INFINITY, nsum = 0.f;
+            float nsum = 0.f;
+            const half2v zero2 = {(half_t)0.0f, (half_t)0.0f};
 #pragma unroll
-            for (int i = 0; i < EPT; ++i) {
-                const float ei = exp_fast((float)yd[i] - mx);
-                const half_t q = (half_t)div_rn(ei, z);
-                half_t di = (half_t)((float)p[i] - (float)q);
-                di = di > (half_t)0.0f ? di : (half_t)0.0f;      // relu_; NaN p stays out (compares false)
-                p[i] = di;                                       // p now holds the unnormalised residual
-                lint += (uint32_t)((float)di * 16777216.0f);
-                if (!REPLACE && mine && i == tok_local) {
-                    yd[i] = (half_t)(-INFINITY);
-                } else {
-                    nmax = fmaxf(nmax, (float)yd[i]);
-                    nsum += ei;
+            for (int k2 = 0; k2 < EPT / 2; ++k2) {
+                half2v pi = p[k2];
+                if (scaled) { pi[0] = (half_t)div_sf((float)pi[0]); pi[1] = (half_t)div_sf((float)pi[1]); }
+                half2v q;
+                q[0] = (half_t)div_z(e[2 * k2]); q[1] = (half_t)div_z(e[2 * k2 + 1]);
+                // relu_(p - q) in packed fp16 (one rounding, like the reference's fp16 tensor op); a NaN difference
+                // becomes 0 (max returns the number), as `d > 0 ? d : 0` did
+                const half2v di = __builtin_elementwise_max(pi - q, zero2);
+                p[k2] = di;                                      // p now holds the unnormalised residual
+                lint += (uint32_t)((float)di[0] * 16777216.0f) + (uint32_t)((float)di[1] * 16777216.0f);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int i = 2 * k2 + h2;
+                    if (!REPLACE && mine && i == tok_local) { e[i] = 0.f; masked |= 1u << i; }
+                    nsum += e[i];                                // fresh sum of the draft without the rejected token
                 }
             }
-            const Red3 red = block_red3(lint, nmax, nsum, s_u, s_m, s_s);   // also orders the s_tok reads above
-            const half_t s16 = grid_sum_to_f16(red.isum);
+            const Red3 red = block_red3(lint, 0.f, nsum, s_u, s_m, s_s);   // also orders the s_tok reads above
             if (red.isum == 0ull) nan_flag = 1;                  // 0/0 -> NaN residual (utils.py:7)
-            const float sf = (float)s16;
-#pragma unroll
-            for (int i = 0; i < EPT; ++i) p[i] = nan_flag ? (half_t)NAN : (half_t)div_rn((float)p[i], sf);
+            sf = (float)grid_sum_to_f16(red.isum);
+            scaled = true;
             nrej = jc + 1;
             if (nan_flag) break;          // every later comparison with NaN is false: all rejected
             if (REPLACE) continue;        // q is unchanged
-            if (red.fmax != mx) {         // the removed token was the maximum: rebase the exponentials
-                mx = red.fmax;
+            z = red.fsum;
+            if (e_tok == 1.0f) {          // the rejected token sat at the maximum (exp(0) is exactly 1): rebase the
+                mx = block_max_f32<VER_WAVES>(load_y(e), s_f);   // exponentials on the maximum of what is left
                 lsum = 0.f;
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) lsum += exp_fast((float)yd[i] - mx);
+                for (int i = 0; i < EPT; ++i) { e[i] = exp_fast(e[i] - mx); lsum += e[i]; }
                 z = block_sum_f32<VER_WAVES>(lsum, s_f);
-            } else {
-                z = red.fsum;
             }
         }
         if (nan_flag) nrej = nc;
@@ -288,6 +346,11 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
 
     int bonus = -1;
     if (accepted < 0 && !nan_flag) {
+        if (scaled) {                     // materialise the normalised residual for the draw
+            const RcpDiv div_sf(sf);
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) H2(p, i) = (half_t)div_sf((float)H2(p, i));
+        }
         bonus = block_inverse_cdf<EPT>(p, vocab, t, u24);
         if (bonus < 0) nan_flag = 1;      // empty distribution: treated like the NaN residual
     }
@@ -300,13 +363,15 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
 }
 
 // One wave.  Walk root -> accepted children; side effects of Tree/SpecTree.py:156,222,224.
-__global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const int32_t* __restrict__ child_off,
-                                   const int32_t* __restrict__ child_ids, int n_tree, int vocab, int gt,
-                                   void* ws_raw, int32_t* result, int mode, const int64_t* __restrict__ tgt_tokens) {
+__global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, int token_capacity,
+                                   const int32_t* __restrict__ child_off, const int32_t* __restrict__ child_ids,
+                                   int n_tree, int vocab, int gt_arg, void* ws_raw, int32_t* result, int mode,
+                                   const int64_t* __restrict__ tgt_tokens, int32_t* d_step, int32_t* d_ring) {
     // mode 0: stochastic (Sequoia), 1: token equality against tgt (greedy argmax or caller-supplied samples),
     //      2: stochastic without the draft-logit side effects (SpecInfer)
     const VerifyWs ws = ws_layout(ws_raw, n_tree);
     if (threadIdx.x != 0) return;
+    const int gt = step_gt(d_step, gt_arg);
     const int greedy = (mode & 3) == 1;
     const int gather_first = greedy || (mode & 4);
     mode &= 3;
@@ -349,6 +414,12 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
             bonus = ws.bonus[node];
         }
     }
+    const int a = gt + n_acc;
+    if (!terminal && token_capacity > 0 && a >= token_capacity) {
+        // no slot for the bonus token (a fully accepted chain that ends at max_length): the reference raises
+        // IndexError at `self.tokens[accept_length] = ...` (Tree/SpecTree.py:222); here the step becomes terminal
+        terminal = 1; reason = 3; bonus = -1;
+    }
     // tokens[:a] = tokens[accept_list]: slots ascending and dst <= src, so the sequential
     // in-place move never overwrites a source it still needs.
     // Order of the two writes follows the reference: SpecTree / SpecInferTree store the bonus token at slot a
@@ -356,7 +427,6 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
     // n_acc + 1 on the accepted path, e.g. a fully accepted 8x8 tree) is committed with the bonus token's id;
     // GreedyTree / GreedySTree gather first (Tree/GreedyTree.py:204-206).  Reproduced for token parity; callers that
     // want the lossless order pass SQ_VERIFY_GATHER_FIRST with the bonus uniform.
-    const int a = gt + n_acc;
     if (!gather_first && !terminal) tokens[a] = bonus;
     for (int j = 0; j < n_acc; ++j) tokens[gt + j] = tokens[ws.path[j] + gt - 1];
     if (gather_first && !terminal) tokens[a] = bonus;
@@ -367,16 +437,34 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, const 
     result[SQ_RES_REASON] = reason;
     result[SQ_RES_GT] = gt;
     result[SQ_RES_LAST_NODE] = node;
-    result[7] = 0;
+    result[7] = d_step ? d_step[SQ_STEP_INDEX] : 0;
+    if (d_step) {
+        // device-driven step: the next step starts at new_gt = a + 1 (the bonus token is committed at slot a)
+        d_step[SQ_STEP_NEXT_GT] = terminal ? gt : a + 1;
+        if (terminal) d_step[SQ_STEP_ACTIVE] = 0;
+        if (d_ring) {                                                 // copy of the header for the host, one slot per step
+            int32_t* slot = d_ring + ((uint32_t)d_step[SQ_STEP_INDEX] % SQ_RESULT_RING) * SQ_RESULT_INTS;
+            for (int i = 0; i < SQ_RESULT_INTS; ++i) slot[i] = result[i];
+        }
+    }
 }
+
+struct StepArgs {                       // optional device-driven extras of the verify entry points
+    int token_capacity;
+    int32_t* d_step;
+    const uint32_t* d_bonus;
+    int n_bonus;
+    int32_t* d_ring;
+};
 
 static int verify_stochastic_impl(const void* target_logits, void* draft_logits, int64_t* tokens, const void* r,
                                   const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab, int gt,
                                   float temperature, uint32_t bonus_u24, void* workspace, int32_t* d_result, void* stream,
-                                  bool replace) {
+                                  bool replace, const StepArgs& sa) {
     if (!target_logits || !draft_logits || !tokens || !r || !d_child_off || !workspace || !d_result) return SQ_EINVAL;
-    if (n_tree <= 0 || n_tree > SQ_MAX_TREE || vocab <= 0 || gt < 1 || !(temperature > 0.f)) return SQ_EINVAL;
+    if (n_tree <= 0 || n_tree > SQ_MAX_TREE || vocab <= 0 || (!sa.d_step && gt < 1) || !(temperature > 0.f)) return SQ_EINVAL;
     if (n_tree > 1 && !d_child_ids) return SQ_EINVAL;
+    if (sa.d_bonus && sa.n_bonus <= 0) return SQ_EINVAL;
     if ((vocab & 7) || ((uintptr_t)target_logits & 15) || ((uintptr_t)draft_logits & 15)) return SQ_EUNSUPPORTED;
     const int gather_first = (bonus_u24 & SQ_VERIFY_GATHER_FIRST) ? 4 : 0;
     bonus_u24 &= ~SQ_VERIFY_GATHER_FIRST;
@@ -386,33 +474,37 @@ static int verify_stochastic_impl(const void* target_logits, void* draft_logits,
 #define SQ_LAUNCH(EPT, REP)                                                                                     \
     hipLaunchKernelGGL((verify_nodes_kernel<EPT, REP>), g, b, 0, st, (const half_t*)target_logits,               \
                        (const half_t*)draft_logits, (const int64_t*)tokens, (const half_t*)r, d_child_off,        \
-                       d_child_ids, n_tree, vocab, gt, temperature, bonus_u24, workspace)
+                       d_child_ids, n_tree, vocab, gt, temperature, bonus_u24, workspace, (const int32_t*)sa.d_step, \
+                       sa.d_bonus, sa.n_bonus)
     if (vocab <= 8 * VER_THREADS) { if (replace) SQ_LAUNCH(8, true); else SQ_LAUNCH(8, false); }
     else if (vocab <= 32 * VER_THREADS) { if (replace) SQ_LAUNCH(32, true); else SQ_LAUNCH(32, false); }
     else return SQ_EUNSUPPORTED;
 #undef SQ_LAUNCH
     int rc = sq_check_launch();
     if (rc != SQ_OK) return rc;
-    hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, st, (half_t*)draft_logits, tokens, d_child_off,
-                       d_child_ids, n_tree, vocab, gt, workspace, d_result, (replace ? 2 : 0) | gather_first,
-                       (const int64_t*)nullptr);
+    hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, st, (half_t*)draft_logits, tokens, sa.token_capacity,
+                       d_child_off, d_child_ids, n_tree, vocab, gt, workspace, d_result, (replace ? 2 : 0) | gather_first,
+                       (const int64_t*)nullptr, sa.d_step, sa.d_ring);
     return sq_check_launch();
 }
 
-extern "C" int sq_verify_stochastic_f16(const void* target_logits, void* draft_logits, int64_t* tokens, const void* r,
-                                        const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab,
-                                        int gt, float temperature, uint32_t bonus_u24, void* workspace,
-                                        int32_t* d_result, void* stream) {
+extern "C" int sq_verify_stochastic_f16(const void* target_logits, void* draft_logits, int64_t* tokens, int token_capacity,
+                                        const void* r, const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree,
+                                        int vocab, int gt, float temperature, uint32_t bonus_u24, void* workspace,
+                                        int32_t* d_result, int32_t* d_step, const uint32_t* d_bonus_u24, int n_bonus,
+                                        int32_t* d_result_ring, void* stream) {
+    const StepArgs sa{token_capacity, d_step, d_bonus_u24, n_bonus, d_result_ring};
     return verify_stochastic_impl(target_logits, draft_logits, tokens, r, d_child_off, d_child_ids, n_tree, vocab, gt,
-                                  temperature, bonus_u24, workspace, d_result, stream, false);
+                                  temperature, bonus_u24, workspace, d_result, stream, false, sa);
 }
 
-extern "C" int sq_verify_specinfer_f16(const void* target_logits, const void* draft_logits, int64_t* tokens, const void* r,
-                                       const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab,
-                                       int gt, float temperature, uint32_t bonus_u24, void* workspace,
-                                       int32_t* d_result, void* stream) {
+extern "C" int sq_verify_specinfer_f16(const void* target_logits, const void* draft_logits, int64_t* tokens,
+                                       int token_capacity, const void* r, const int32_t* d_child_off,
+                                       const int32_t* d_child_ids, int n_tree, int vocab, int gt, float temperature,
+                                       uint32_t bonus_u24, void* workspace, int32_t* d_result, void* stream) {
+    const StepArgs sa{token_capacity, nullptr, nullptr, 0, nullptr};
     return verify_stochastic_impl(target_logits, (void*)draft_logits, tokens, r, d_child_off, d_child_ids, n_tree, vocab,
-                                  gt, temperature, bonus_u24, workspace, d_result, stream, true);
+                                  gt, temperature, bonus_u24, workspace, d_result, stream, true, sa);
 }
 
 // ---- i.i.d. draws from softmax(logits / T) (SpecInfer's draft expansion, Tree/SpecInferTree.py:104-109) ------------
@@ -426,7 +518,7 @@ sample_iid_kernel(const half_t* __restrict__ logits, int64_t ld, const int32_t* 
     __shared__ float s_f[VER_WAVES];
     const int t = threadIdx.x, row = blockIdx.x;
     const int src = row_ids ? row_ids[row] : row;
-    half_t p[EPT];
+    half2v p[EPT / 2];
     row_softmax_f16<EPT>(logits + (size_t)src * ld, vocab, temperature, t, p, s_f);
     const int take = branch ? branch[row] : k;
     const int64_t base = out_off ? (int64_t)out_off[row] : (int64_t)row * k;
@@ -470,7 +562,7 @@ top_p_filter_kernel(half_t* __restrict__ logits, int64_t ld, int vocab, float to
     __shared__ unsigned long long s_ct[VER_WAVES][EPT / 8];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     half_t* x = logits + (size_t)blockIdx.x * ld;
-    half_t p[EPT];
+    half2v p[EPT / 2];
     row_softmax_f16<EPT>(x, vocab, temperature, t, p, s_f);
     uint32_t okey[EPT];          // ordered key of the raw logit (sort key of the reference)
 #pragma unroll
@@ -479,14 +571,14 @@ top_p_filter_kernel(half_t* __restrict__ logits, int64_t ld, int vocab, float to
         half8 v;
         if (e0 < vocab) v = *(const half8*)(x + e0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) okey[c * 8 + j] = (e0 + j < vocab) ? f16_to_ordered(v[j]) : 0u;
+        for (int j = 0; j < 8; ++j) okey[c * 8 + j] = (e0 < vocab) ? f16_to_ordered(v[j]) : 0u;
     }
     const half_t th16 = (half_t)top_p;
     auto mass_above = [&](uint32_t kappa) {          // exact sum of w_i over okey_i > kappa
         uint32_t part = 0u;
 #pragma unroll
         for (int i = 0; i < EPT; ++i)
-            if (okey[i] > kappa && v_elem(i >> 3, t, i & 7) < vocab) part += (uint32_t)((float)p[i] * 16777216.0f);
+            if (okey[i] > kappa && v_elem(i >> 3, t, 0) < vocab) part += (uint32_t)((float)H2(p, i) * 16777216.0f);
         unsigned long long ws = wave_sum_u32_wide_dpp(part);
         if (lane == 0) s_u[wave] = ws;
         __syncthreads();
@@ -512,7 +604,7 @@ top_p_filter_kernel(half_t* __restrict__ logits, int64_t ld, int vocab, float to
         uint32_t sv = 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (okey[c * 8 + j] == kmin && v_elem(c, t, j) < vocab) sv += (uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+            if (okey[c * 8 + j] == kmin && v_elem(c, t, 0) < vocab) sv += (uint32_t)((float)H2(p, c * 8 + j) * 16777216.0f);
         tsum[c] = sv;
         const unsigned long long wsum = wave_sum_u32_wide_dpp(sv);
         if (lane == 0) s_ct[wave][c] = wsum;
@@ -545,9 +637,9 @@ top_p_filter_kernel(half_t* __restrict__ logits, int64_t ld, int vocab, float to
                 bool remove = k < kmin;
                 if (k == kmin) {
                     remove = grid_sum_to_f16(acc) > th16;          // mass ranked strictly before this tie
-                    acc += (unsigned long long)(uint32_t)((float)p[c * 8 + j] * 16777216.0f);
+                    acc += (unsigned long long)(uint32_t)((float)H2(p, c * 8 + j) * 16777216.0f);
                 }
-                if (remove && (e0 + j < vocab)) { v[j] = (half_t)(-INFINITY); dirty = true; }
+                if (remove && (e0 < vocab)) { v[j] = (half_t)(-INFINITY); dirty = true; }
             }
             if (dirty) *(half8*)(x + e0) = v;
         }
@@ -597,11 +689,12 @@ argmax_rows_kernel(const half_t* __restrict__ logits, int vocab, int n_tree, voi
     if (t == 0) ws_layout(ws_raw, n_tree).tgt[blockIdx.x] = (int64_t)(0xffffffffu - (uint32_t)(win & 0xffffffffu));
 }
 
-extern "C" int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens, const int32_t* d_child_off,
-                                    const int32_t* d_child_ids, int n_tree, int vocab, int gt, void* workspace,
-                                    int32_t* d_result, void* stream) {
+extern "C" int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens, int token_capacity,
+                                    const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab, int gt,
+                                    void* workspace, int32_t* d_result, int32_t* d_step, int32_t* d_result_ring,
+                                    void* stream) {
     if (!target_logits || !tokens || !d_child_off || !workspace || !d_result) return SQ_EINVAL;
-    if (n_tree <= 0 || n_tree > SQ_MAX_TREE || vocab <= 0 || gt < 1) return SQ_EINVAL;
+    if (n_tree <= 0 || n_tree > SQ_MAX_TREE || vocab <= 0 || (!d_step && gt < 1)) return SQ_EINVAL;
     if (n_tree > 1 && !d_child_ids) return SQ_EINVAL;
     if ((vocab & 7) || ((uintptr_t)target_logits & 15)) return SQ_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -616,20 +709,21 @@ extern "C" int sq_verify_greedy_f16(const void* target_logits, int64_t* tokens, 
         return SQ_EUNSUPPORTED;
     int rc = sq_check_launch();
     if (rc != SQ_OK) return rc;
-    hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, st, (half_t*)nullptr, tokens, d_child_off, d_child_ids,
-                       n_tree, vocab, gt, workspace, d_result, 1, (const int64_t*)nullptr);
+    hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, st, (half_t*)nullptr, tokens, token_capacity, d_child_off,
+                       d_child_ids, n_tree, vocab, gt, workspace, d_result, 1, (const int64_t*)nullptr, d_step, d_result_ring);
     return sq_check_launch();
 }
 
 // token-equality walk against caller-supplied target tokens (GreedySTree: one token SAMPLED per node from the
 // target distribution instead of the argmax, Tree/GreedySTree.py:188-190,196-214)
-extern "C" int sq_verify_tokens_f16(const int64_t* d_target_tokens, int64_t* tokens, const int32_t* d_child_off,
-                                    const int32_t* d_child_ids, int n_tree, int gt, void* workspace, int32_t* d_result,
-                                    void* stream) {
+extern "C" int sq_verify_tokens_f16(const int64_t* d_target_tokens, int64_t* tokens, int token_capacity,
+                                    const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int gt,
+                                    void* workspace, int32_t* d_result, void* stream) {
     if (!d_target_tokens || !tokens || !d_child_off || !workspace || !d_result) return SQ_EINVAL;
     if (n_tree <= 0 || n_tree > SQ_MAX_TREE || gt < 1) return SQ_EINVAL;
     if (n_tree > 1 && !d_child_ids) return SQ_EINVAL;
-    hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (half_t*)nullptr, tokens, d_child_off,
-                       d_child_ids, n_tree, 0, gt, workspace, d_result, 1, d_target_tokens);
+    hipLaunchKernelGGL(verify_walk_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (half_t*)nullptr, tokens, token_capacity,
+                       d_child_off, d_child_ids, n_tree, 0, gt, workspace, d_result, 1, d_target_tokens, (int32_t*)nullptr,
+                       (int32_t*)nullptr);
     return sq_check_launch();
 }

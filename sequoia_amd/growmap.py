@@ -140,4 +140,5 @@ class GrowMap:
             levels.append(dict(row_ids=t(lv.row_ids), branch=t(lv.branch), out_off=t(lv.out_off), k=lv.k,
                                total=lv.total, first_child=lv.first_child, n_rows=len(lv.row_ids)))
         return dict(child_off=t(self.child_off), child_ids=t(self.child_ids) if self.size > 1 else None,
-                    bitmask=t(self.bitmask.view(np.int64)), depth=t(self.depth), levels=levels)
+                    bitmask=t(self.bitmask.view(np.int64)), depth=t(self.depth), depth32=t(self.depth.astype(np.int32)),
+                    max_depth=int(self.depth.max()), levels=levels)

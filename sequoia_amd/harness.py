@@ -61,7 +61,11 @@ def build(cfg, device, pair, seed_d=1, seed_t=2):
 class Loop:
     """simulation_fast (tests/testbed.py:45-95) as a resumable step iterator."""
 
-    def __init__(self, cfg, draft, target, gm, device, prompts, use_graphs=True, T=0.6, top_p=1.0, max_new=256, vocab=32000):
+    def __init__(self, cfg, draft, target, gm, device, prompts, use_graphs=True, T=0.6, top_p=1.0, max_new=256, vocab=32000,
+                 pipelined=False):
+        """pipelined: after a prompt's first (prefill-bearing) step the loop is driven by the device
+        (Tree/step_graph.py): whole steps are enqueued as one hipGraph each, up to two in flight, and their result
+        records are read one step late -- same tokens as the synchronous loop, no host round trip between steps."""
         from sequoia_amd.Tree.GreedyTree import GreedyTree
         from sequoia_amd.Tree.SpecTree import SpecTree
         from sequoia_amd.Tree.Tree import growmap_on_device
@@ -81,6 +85,7 @@ class Loop:
         self.pi = 0
         self.tree = None
         self.cur_len = 0
+        self.pipelined = bool(pipelined) and str(device).startswith("cuda") and not cfg.get("tp")
 
     def _new_prompt(self):
         self.draft.clear_kv(); self.target.clear_kv()
@@ -92,29 +97,55 @@ class Loop:
                              max_length=M, max_target_seq=M, grow_map=self.grow_map, attn_mask=self.attn_mask,
                              sequence=None, new_tokens_buffer=None, parents_buffer=None,
                              position_ids=self.position_ids, residual_graph=None, sampling_callables=None,
-                             sample_gather_indices=None, vocab_size=self.vocab)
+                             sample_gather_indices=None, vocab_size=self.vocab,
+                             **(dict(step_graph=True) if self.pipelined else {}))
         self.cur_len = len(p)
 
-    def run_steps(self, k_steps, on_step=None):
+    def run_steps(self, k_steps, on_step=None, on_accept=None):
         """Run exactly k_steps speculation steps; per-prompt setup (tree constructor + draft
         prefill) is outside the timed brackets like the reference (tests/testbed.py:67-79).
-        `on_step(tree, terminate)` is called after every verify().  Returns (seconds, new_tokens, steps)."""
+        `on_step(tree, terminate)` is called after every verify() (synchronous mode), `on_accept(accept_length)` after
+        every step in both modes.  Returns (seconds, new_tokens, steps)."""
         total_t, new_tok, done = 0.0, 0, 0
         while done < k_steps:
             if self.tree is None:
                 self._new_prompt()
             _sync(self.device)
             t1 = time.perf_counter()
+            tree = self.tree
+            piped = self.pipelined and tree.state is not None
             while done < k_steps and self.tree is not None:
-                self.tree.construct_grow_map()
-                valid, _, _, terminate = self.tree.verify()
-                new_tok += valid.shape[0] - self.cur_len
-                self.cur_len = valid.shape[0]
+                if piped and tree._pipe is not None:
+                    # device-driven: keep up to two whole-step graphs in flight, read results one step late
+                    while (len(tree._pipe["inflight"]) < 2 and tree.can_enqueue(self.max_new)
+                           and done + len(tree._pipe["inflight"]) < k_steps):
+                        tree.enqueue_step()
+                    if not tree._pipe["inflight"]:
+                        tree.end_pipeline()            # out of run-ahead room: finish the prompt synchronously
+                        continue
+                    a, _, bonus, terminate = tree.collect_step()
+                    length = a if terminate else a + 1
+                    last = bonus
+                else:
+                    tree.construct_grow_map()
+                    valid, a, _, terminate = tree.verify()
+                    length = valid.shape[0]
+                    last = int(valid[-1])              # the reference's EOS test reads the last token (tests/testbed.py:80)
+                    if on_step is not None:
+                        on_step(tree, terminate)
+                    if (piped and not (terminate or length >= self.max_new or last in (0, 2)) and not tree._no_room):
+                        tree.begin_pipeline()          # the target is prefilled: hand the loop to the device
+                new_tok += length - self.cur_len
+                self.cur_len = length
                 done += 1
-                if on_step is not None:
-                    on_step(self.tree, terminate)
-                if terminate or self.cur_len >= self.max_new or int(valid[-1]) in (0, 2):
+                if on_accept is not None:
+                    on_accept(int(a))
+                if terminate or self.cur_len >= self.max_new or last in (0, 2):
+                    if piped:
+                        tree.end_pipeline()
                     self.tree = None
+            if piped and self.tree is not None:
+                tree.end_pipeline()                    # k_steps reached mid-prompt: back to host-side state
             _sync(self.device)
             total_t += time.perf_counter() - t1
         return total_t, new_tok, done

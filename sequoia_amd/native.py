@@ -17,6 +17,8 @@ SQ_MAX_TOPK = 128
 SQ_RESULT_INTS = 64
 SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_BONUS, SQ_RES_TERMINAL = 0, 1, 2, 3
 SQ_RES_REASON, SQ_RES_GT, SQ_RES_LAST_NODE, SQ_RES_SLOTS = 4, 5, 6, 8
+SQ_STEP_GT, SQ_STEP_NEXT_GT, SQ_STEP_INDEX, SQ_STEP_ACTIVE, SQ_STEP_INTS = 0, 1, 2, 3, 8
+SQ_RESULT_RING = 4
 SQ_ATT_OUT_FRAG = 0x100
 SQ_VERIFY_GATHER_FIRST = 0x80000000
 
@@ -30,7 +32,7 @@ PROTOTYPES = {
     "sq_tree_bitmask_from_successors": (_i, [_vp, _vp, _i, _vp, _i]),
     "sq_tree_mask_dense_f16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "sq_kv_scatter_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "sq_kv_compact_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "sq_kv_compact_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sq_kv_clear_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_rope_kv_write_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_tree_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _i, _i, _i,
@@ -38,16 +40,20 @@ PROTOTYPES = {
     "sq_rope_tree_attention_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i,
                                         _vp, _i, _vp, _vp]),
     "sq_store_i32": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
-    "sq_sample_wor_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
-    "sq_topk_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sq_sample_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "sq_logits_stats_f16": (_i, [_vp, _i64, _vp, _i, _i, _f, _vp, _i, _vp, _i64, _vp]),
+    "sq_sample_wor_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sq_topk_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sq_stage_inputs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "sq_stage_tree_inputs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "sq_verify_workspace_bytes": (C.c_size_t, [_i]),
     "sq_sample_iid_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
-    "sq_verify_specinfer_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp]),
-    "sq_verify_tokens_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
-    "sq_verify_stochastic_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp]),
+    "sq_verify_specinfer_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp]),
+    "sq_verify_tokens_f16": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "sq_verify_stochastic_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp, _vp, _i, _vp,
+                                      _vp]),
     "sq_top_p_filter_f16": (_i, [_vp, _i64, _i, _i, _f, _f, _vp]),
-    "sq_verify_greedy_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sq_verify_greedy_f16": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sq_rmsnorm_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_silu_mul_f16": (_i, [_vp, _vp, _i, _i, _vp]),
     "sq_add_rmsnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

@@ -64,8 +64,9 @@ class HipOps:
         check(self.lib.sq_kv_scatter_f16(k_layer.data_ptr(), v_layer.data_ptr(), new_k.data_ptr(), new_v.data_ptr(),
                                          storage_ids.data_ptr(), q_len, h_kv, m, d, self._stream()), "sq_kv_scatter_f16")
 
-    def kv_compact(self, k_cache, v_cache, slots, count, max_count, dst_offset, zero_end):
-        """k_cache/v_cache: [L, 1, H, M, D]; slots: int32 device tensor; count: int32[1] device tensor or None."""
+    def kv_compact(self, k_cache, v_cache, slots, count, max_count, dst_offset, zero_end, dst_offset_dev=None):
+        """k_cache/v_cache: [L, 1, H, M, D]; slots: int32 device tensor; count: int32[1] device tensor or None;
+        dst_offset_dev: int32 device scalar overriding dst_offset (device-driven step)."""
         _need(k_cache, torch.float16, "k_cache"); _need(v_cache, torch.float16, "v_cache")
         if max_count > 0:
             _need(slots, torch.int32, "slots")
@@ -74,8 +75,8 @@ class HipOps:
         n_layers = k_cache.shape[0]
         h_kv, m, d = k_cache.shape[-3:]
         check(self.lib.sq_kv_compact_f16(k_cache.data_ptr(), v_cache.data_ptr(), n_layers, h_kv, m, d, _ptr(slots),
-                                         _ptr(count), max_count, dst_offset, zero_end, self._stream()),
-              "sq_kv_compact_f16")
+                                         _ptr(count), max_count, dst_offset, zero_end, _ptr(dst_offset_dev),
+                                         self._stream()), "sq_kv_compact_f16")
 
     def kv_clear(self, k_cache, v_cache, used_rows):
         _need(k_cache, torch.float16, "k_cache"); _need(v_cache, torch.float16, "v_cache")
@@ -113,6 +114,19 @@ class HipOps:
         check(self.lib.sq_stage_inputs(dst_ids.data_ptr(), src_ids.data_ptr(), dst_pos.data_ptr(), src_pos.data_ptr(),
                                        dst_storage.data_ptr(), src_storage.data_ptr(), q_len, _ptr(ctx), int(q_slot0),
                                        int(gt), int(kv_len), self._stream()), "sq_stage_inputs")
+
+    def stage_tree_inputs(self, dst_ids, dst_pos, dst_storage, ctx, tokens, depth, n_tree, rel_slot0, rel_kv_len, step,
+                          advance=False):
+        """Device-driven staging of a tree forward: queries at slots [gt + rel_slot0, ... + q_len), gt from `step`."""
+        q_len = dst_ids.numel()
+        for t, n in ((dst_ids, "dst_ids"), (dst_pos, "dst_pos"), (dst_storage, "dst_storage"), (tokens, "tokens")):
+            _need(t, torch.int64, n)
+        _need(ctx, torch.int32, "ctx"); _need(depth, torch.int32, "depth"); _need(step, torch.int32, "step")
+        assert dst_pos.numel() == q_len and dst_storage.numel() == q_len and depth.numel() >= n_tree
+        check(self.lib.sq_stage_tree_inputs(dst_ids.data_ptr(), dst_pos.data_ptr(), dst_storage.data_ptr(), ctx.data_ptr(),
+                                            tokens.data_ptr(), depth.data_ptr(), int(n_tree), q_len, int(rel_slot0),
+                                            int(rel_kv_len), step.data_ptr(), 1 if advance else 0, self._stream()),
+              "sq_stage_tree_inputs")
 
     def tree_attention(self, q, k_layer, v_layer, out, kv_len, scale, dense_mask=None, q_slot0=0, gt=0, n_tree=0,
                        bitmask=None, ctx=None, out_frag=False):
@@ -161,28 +175,71 @@ class HipOps:
         return out
 
     # ---- a2 ---------------------------------------------------------------------------------
-    def sample_wor(self, logits, rand, row_ids, k, temperature, out, branch=None, out_off=None):
-        """logits/rand: 2-D fp16 with unit inner stride; row_ids: int32 device tensor or None."""
+    def _sample_ws(self, device, n_rows, vocab, k):
+        """Sampler scratch, one buffer per device, grown outside graph captures (sized generously on first use)."""
+        need = int(self.lib.sq_sample_workspace_bytes(max(int(n_rows), 1), int(vocab), int(k)))
+        key = str(device)
+        ws = getattr(self, "_samp_ws", {}).get(key)
+        if ws is None or ws.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise native.SequoiaNativeError("sampler workspace must be sized before graph capture (run the step eagerly once)")
+            want = max(need, int(self.lib.sq_sample_workspace_bytes(native.SQ_MAX_TREE, int(vocab), 32)))
+            ws = torch.empty(want, dtype=torch.uint8, device=device)
+            if not hasattr(self, "_samp_ws"):
+                self._samp_ws = {}
+            self._samp_ws[key] = ws
+        return ws
+
+    @staticmethod
+    def stats_shape(n_rows, vocab):
+        return (n_rows, (vocab + 4095) // 4096, 2)
+
+    def logits_stats(self, logits, temperature, stats, row_ids=None, by_source_row=False, copy_dst=None):
+        """Per-part softmax statistics of logits rows (optionally copying the rows to copy_dst[r])."""
+        _need(logits, torch.float16, "logits", contiguous=False); _need(stats, torch.float32, "stats")
+        assert logits.dim() == 2 and logits.stride(1) == 1
+        n_rows = row_ids.shape[0] if row_ids is not None else logits.shape[0]
+        if row_ids is not None:
+            _need(row_ids, torch.int32, "row_ids")
+        ld_dst = 0
+        if copy_dst is not None:
+            _need(copy_dst, torch.float16, "copy_dst", contiguous=False)
+            assert copy_dst.stride(1) == 1 and copy_dst.shape[0] >= n_rows and copy_dst.shape[1] == logits.shape[1]
+            ld_dst = copy_dst.stride(0)
+        check(self.lib.sq_logits_stats_f16(logits.data_ptr(), logits.stride(0), _ptr(row_ids), n_rows, logits.shape[1],
+                                           float(temperature), stats.data_ptr(), 1 if by_source_row else 0,
+                                           _ptr(copy_dst), ld_dst, self._stream()), "sq_logits_stats_f16")
+        return stats
+
+    def sample_wor(self, logits, rand, row_ids, k, temperature, out, branch=None, out_off=None, out_base=None, stats=None):
+        """logits/rand: 2-D fp16 with unit inner stride; row_ids: int32 device tensor or None; out_base: int32 device
+        scalar added to every output index; stats: per-part statistics of the source rows (logits_stats(by_source_row))."""
         _need(logits, torch.float16, "logits", contiguous=False); _need(rand, torch.float16, "rand", contiguous=False)
         assert logits.stride(1) == 1 and rand.stride(1) == 1
         _need(out, torch.int64, "out", contiguous=False)
         n_rows = row_ids.shape[0] if row_ids is not None else logits.shape[0]
         if row_ids is not None:
             _need(row_ids, torch.int32, "row_ids")
+        if stats is not None:
+            _need(stats, torch.float32, "stats")
+        ws = self._sample_ws(logits.device, n_rows, logits.shape[1], k)
         check(self.lib.sq_sample_wor_f16(logits.data_ptr(), logits.stride(0), rand.data_ptr(), rand.stride(0),
                                          _ptr(row_ids), n_rows, logits.shape[1], k, float(temperature), out.data_ptr(),
-                                         _ptr(branch), _ptr(out_off), self._stream()), "sq_sample_wor_f16")
+                                         _ptr(branch), _ptr(out_off), _ptr(out_base), _ptr(stats), ws.data_ptr(),
+                                         self._stream()), "sq_sample_wor_f16")
         return out
 
-    def topk(self, logits, row_ids, k, out, branch=None, out_off=None):
+    def topk(self, logits, row_ids, k, out, branch=None, out_off=None, out_base=None):
         _need(logits, torch.float16, "logits", contiguous=False)
         assert logits.stride(1) == 1
         _need(out, torch.int64, "out", contiguous=False)
         n_rows = row_ids.shape[0] if row_ids is not None else logits.shape[0]
         if row_ids is not None:
             _need(row_ids, torch.int32, "row_ids")
+        ws = self._sample_ws(logits.device, n_rows, logits.shape[1], k)
         check(self.lib.sq_topk_f16(logits.data_ptr(), logits.stride(0), _ptr(row_ids), n_rows, logits.shape[1], k,
-                                   out.data_ptr(), _ptr(branch), _ptr(out_off), self._stream()), "sq_topk_f16")
+                                   out.data_ptr(), _ptr(branch), _ptr(out_off), _ptr(out_base), ws.data_ptr(),
+                                   self._stream()), "sq_topk_f16")
         return out
 
     # ---- a6 / a7 / a8 -----------------------------------------------------------------------
@@ -191,15 +248,25 @@ class HipOps:
         return torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)
 
     def verify_stochastic(self, target_logits, draft_logits, tokens, r, child_off, child_ids, n_tree, gt, temperature,
-                          u24, workspace, result):
+                          u24, workspace, result, step=None, bonus_table=None, result_ring=None):
+        """step / bonus_table / result_ring: the device-driven form (gt and the bonus uniform read on the device)."""
         _need(target_logits, torch.float16, "target_logits"); _need(draft_logits, torch.float16, "draft_logits")
         _need(tokens, torch.int64, "tokens"); _need(r, torch.float16, "r")
         _need(child_off, torch.int32, "child_off"); _need(result, torch.int32, "result")
         vocab = target_logits.shape[-1]
         assert draft_logits.shape[-1] == vocab and target_logits.shape[0] >= n_tree and draft_logits.shape[0] >= n_tree
+        if step is not None:
+            _need(step, torch.int32, "step")
+        if bonus_table is not None:
+            _need(bonus_table, torch.int32, "bonus_table")
+        if result_ring is not None:
+            _need(result_ring, torch.int32, "result_ring")
+            assert result_ring.numel() >= native.SQ_RESULT_RING * native.SQ_RESULT_INTS
         check(self.lib.sq_verify_stochastic_f16(target_logits.data_ptr(), draft_logits.data_ptr(), tokens.data_ptr(),
-                                                r.data_ptr(), child_off.data_ptr(), _ptr(child_ids), n_tree, vocab, gt,
-                                                float(temperature), int(u24), workspace.data_ptr(), result.data_ptr(),
+                                                tokens.numel(), r.data_ptr(), child_off.data_ptr(), _ptr(child_ids), n_tree,
+                                                vocab, int(gt), float(temperature), int(u24), workspace.data_ptr(),
+                                                result.data_ptr(), _ptr(step), _ptr(bonus_table),
+                                                0 if bonus_table is None else bonus_table.numel(), _ptr(result_ring),
                                                 self._stream()), "sq_verify_stochastic_f16")
         return result
 
@@ -225,7 +292,7 @@ class HipOps:
         vocab = target_logits.shape[-1]
         assert draft_logits.shape[-1] == vocab and target_logits.shape[0] >= n_tree and draft_logits.shape[0] >= n_tree
         check(self.lib.sq_verify_specinfer_f16(target_logits.data_ptr(), draft_logits.data_ptr(), tokens.data_ptr(),
-                                               r.data_ptr(), child_off.data_ptr(), _ptr(child_ids), n_tree, vocab, gt,
+                                               tokens.numel(), r.data_ptr(), child_off.data_ptr(), _ptr(child_ids), n_tree, vocab, gt,
                                                float(temperature), int(u24), workspace.data_ptr(), result.data_ptr(),
                                                self._stream()), "sq_verify_specinfer_f16")
         return result
@@ -234,7 +301,7 @@ class HipOps:
         _need(target_tokens, torch.int64, "target_tokens"); _need(tokens, torch.int64, "tokens")
         _need(child_off, torch.int32, "child_off"); _need(result, torch.int32, "result")
         assert target_tokens.numel() >= n_tree
-        check(self.lib.sq_verify_tokens_f16(target_tokens.data_ptr(), tokens.data_ptr(), child_off.data_ptr(),
+        check(self.lib.sq_verify_tokens_f16(target_tokens.data_ptr(), tokens.data_ptr(), tokens.numel(), child_off.data_ptr(),
                                             _ptr(child_ids), n_tree, gt, workspace.data_ptr(), result.data_ptr(),
                                             self._stream()), "sq_verify_tokens_f16")
         return result
@@ -247,13 +314,18 @@ class HipOps:
                                            float(top_p), float(temperature), self._stream()), "sq_top_p_filter_f16")
         return logits
 
-    def verify_greedy(self, target_logits, tokens, child_off, child_ids, n_tree, gt, workspace, result):
+    def verify_greedy(self, target_logits, tokens, child_off, child_ids, n_tree, gt, workspace, result, step=None,
+                      result_ring=None):
         _need(target_logits, torch.float16, "target_logits"); _need(tokens, torch.int64, "tokens")
         _need(child_off, torch.int32, "child_off"); _need(result, torch.int32, "result")
         vocab = target_logits.shape[-1]
-        check(self.lib.sq_verify_greedy_f16(target_logits.data_ptr(), tokens.data_ptr(), child_off.data_ptr(),
-                                            _ptr(child_ids), n_tree, vocab, gt, workspace.data_ptr(), result.data_ptr(),
-                                            self._stream()), "sq_verify_greedy_f16")
+        if step is not None:
+            _need(step, torch.int32, "step")
+        if result_ring is not None:
+            _need(result_ring, torch.int32, "result_ring")
+        check(self.lib.sq_verify_greedy_f16(target_logits.data_ptr(), tokens.data_ptr(), tokens.numel(), child_off.data_ptr(),
+                                            _ptr(child_ids), n_tree, vocab, int(gt), workspace.data_ptr(), result.data_ptr(),
+                                            _ptr(step), _ptr(result_ring), self._stream()), "sq_verify_greedy_f16")
         return result
 
     # ---- row-wise glue ------------------------------------------------------------------------

@@ -51,7 +51,7 @@ def build_engines(z, meta, device):
     return draft, target
 
 
-def make_tree(z, meta, draft, target, device, cls=None):
+def make_tree(z, meta, draft, target, device, cls=None, step_graph=None):
     from sequoia_amd.growmap import GrowMap
     from sequoia_amd.Tree.GreedyTree import GreedyTree
     from sequoia_amd.Tree.SpecTree import SpecTree
@@ -68,8 +68,8 @@ def make_tree(z, meta, draft, target, device, cls=None):
                sequence=None, new_tokens_buffer=None, parents_buffer=None,
                position_ids=torch.zeros(M, device=device).long(), residual_graph=None, sampling_callables=None,
                sample_gather_indices=None, vocab_size=meta["vocab"],
-               bonus_uniforms=[int(x) for x in z["bonus_u24"]])
-    tree.commit_order = "reference"             # the traces are runs of the reference itself (bonus stored before the gather)
+               bonus_uniforms=[int(x) for x in z["bonus_u24"]], step_graph=step_graph,
+               commit_order="reference")        # the traces are runs of the reference itself (bonus stored before the gather)
     if meta["mode"] == "specinfer":
         tree.draw_uniforms = [z["draw_u24"][i] for i in range(z["draw_u24"].shape[0])]     # the trace's uniforms, per step
     if meta["mode"] == "greedys":

@@ -19,6 +19,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/sequoia_hip.h but not exported"
     assert declared == set(native.PROTOTYPES), declared ^ set(native.PROTOTYPES)
     assert lib.sq_version() >= 100
+    # the ctypes prototypes carry one argtype per declared parameter (header <-> binding drift)
+    text = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    for name, params in re.findall(r"\b(sq_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        params = params.strip()
+        n_params = 0 if params in ("", "void") else params.count(",") + 1
+        assert n_params == len(native.PROTOTYPES[name][1]), f"{name}: header declares {n_params} parameters, binding " \
+                                                           f"{len(native.PROTOTYPES[name][1])}"
 
 
 def test_host_helper_bitmask_matches_growmap_masks():
@@ -52,8 +59,12 @@ def test_argument_validation_returns_error_codes():
     from sequoia_amd import native
     lib = native.load()
     assert lib.sq_tree_bitmask_from_successors(None, None, 4, None, 1) == native.SQ_EINVAL
-    assert lib.sq_kv_compact_f16(None, None, 1, 1, 8, 64, None, None, 0, 0, 0, None) == native.SQ_EINVAL
-    assert lib.sq_sample_wor_f16(None, 0, None, 0, None, 1, 32000, 4, 0.6, None, None, None, None) == native.SQ_EINVAL
+    assert lib.sq_kv_compact_f16(None, None, 1, 1, 8, 64, None, None, 0, 0, 0, None, None) == native.SQ_EINVAL
+    assert lib.sq_sample_wor_f16(None, 0, None, 0, None, 1, 32000, 4, 0.6, None, None, None, None, None, None,
+                                 None) == native.SQ_EINVAL
+    assert lib.sq_sample_workspace_bytes(34, 32000, 19) >= 34 * 8 * (8 + 19 * 4) and lib.sq_sample_workspace_bytes(0, 32000, 4) == 0
+    assert lib.sq_verify_stochastic_f16(None, None, None, 0, None, None, None, 4, 32000, 5, 0.6, 1, None, None, None, None, 0,
+                                        None, None) == native.SQ_EINVAL
     assert lib.sq_verify_workspace_bytes(128) > 0 and lib.sq_verify_workspace_bytes(0) == 0
     with pytest.raises(native.SequoiaNativeError):
         native.check(native.SQ_EUNSUPPORTED, "x")
