@@ -359,6 +359,16 @@ def main():
             s2, t2, k2 = loop2.run_steps(args.steps)
             tuned = dict(growmap=tuned_name, nodes=gm2.size, value=t2 / s2, unit="tokens/s", ms_per_step=s2 / k2 * 1e3,
                          mean_accepted_len=t2 / k2, steps=k2)
+        host_loop = None
+        if loop.pipelined and world == 1:
+            # the same loop driven from the host (reference API: construct_grow_map + verify, one result read per
+            # step): what the device-driven step graphs buy, measured on the same box and the same prompts
+            draft.clear_kv(); target.clear_kv()
+            torch.manual_seed(17 + rank)
+            loop3 = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs, pipelined=False)
+            loop3.run_steps(args.warmup)
+            s3, t3, k3 = loop3.run_steps(args.steps)
+            host_loop = dict(ms_per_step=s3 / k3 * 1e3, value=t3 / s3, unit="tokens/s", steps=k3)
         autoreg = None
         if not args.no_autoregressive and world == 1:
             # the reference's own comparison point (tests/testbed.py:99-143): the target alone, 1 token / forward
@@ -386,7 +396,8 @@ def main():
                                 gemm="torch TunableOp (hipBLASLt/rocBLAS solution picked per shape)" if gemm_tuned
                                 else "torch default"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs, rccl_ranks=rccl_ranks,
-                    roofline=roof, kernels=kernels, mi355x_growmap=tuned, autoregressive_baseline=autoreg,
+                    roofline=roof, kernels=kernels, host_driven_loop=host_loop, mi355x_growmap=tuned,
+                    autoregressive_baseline=autoreg,
                     cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:

@@ -121,6 +121,14 @@ int sq_rope_kv_write_f16(const void* qkv, int qkv_stride, void* q_out,
                          const int64_t* d_position_ids, const int64_t* d_storage_ids,
                          int q_len, int n_heads, int h_kv, int d, int m, void* stream);
 
+/* The same with the packed q | k | v rows supplied as the split-K partials of the tall-skinny projection
+ * (sq_linear_ts_f16 with splits > 1): fp32 [splits][q_len][qkv_stride]; a value is the sum of its partials in split
+ * order rounded to fp16, i.e. exactly what the projection would have written.                                       */
+int sq_rope_kv_write_slabs_f16(const float* qkv_slab, int splits, int qkv_stride, void* q_out, void* k_layer,
+                               void* v_layer, const void* cos_tab, const void* sin_tab,
+                               const int64_t* d_position_ids, const int64_t* d_storage_ids, int q_len,
+                               int n_heads, int h_kv, int d, int m, void* stream);
+
 /* Tree-batched attention for one layer (LlamaAttention_FI.forward Engine/Llama_modules.py:
  * 124-134 and LlamaAttention_TG.forward :220-248): out = softmax(q k^T * scale + mask) v over
  * key slots [0, kv_len), fp32 softmax, MFMA for q k^T and p v.

@@ -48,6 +48,16 @@ class OracleOps:
                             _np(k_layer), _np(v_layer))
         q_out.copy_(torch.from_numpy(q))
 
+    def rope_kv_write_slabs(self, slab, splits, n_cols, q_out, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads,
+                            h_kv, d):
+        q_len = position_ids.numel()
+        part = _np(slab)[:splits * q_len * n_cols].reshape(splits, q_len, n_cols)
+        acc = np.zeros((q_len, n_cols), dtype=np.float32)
+        for s_ in range(splits):
+            acc = acc + part[s_]
+        self.rope_kv_write(torch.from_numpy(O.h(acc)), q_out, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads,
+                           h_kv, d)
+
     def store_i32(self, dst, values):
         for i, v in enumerate(values):
             dst[i] = int(v)

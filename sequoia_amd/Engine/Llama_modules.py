@@ -60,25 +60,30 @@ class LayerWeights:
 
 
 def attention_core(qkv, layer_idx: int, dims, kv_cache, cos, sin, position_ids, storage_ids, dense_mask,
-                   tree: TreeContext | None, out_frag: bool = False):
-    """qkv: [q, (H + 2 H_kv) D] packed projections.  RoPE + KV slot write + tree-batched attention;
+                   tree: TreeContext | None, out_frag: bool = False, qkv_slab=None):
+    """qkv: [q, (H + 2 H_kv) D] packed projections -- or qkv_slab = (fp32 slab, splits, q_len): the split-K partials of the
+    tall-skinny projection, summed by the RoPE kernel.  RoPE + KV slot write + tree-batched attention;
     returns the attention output [q, H D] (the o_proj input), or with out_frag its fragment-major image
     (the operand layout of the tall-skinny o_proj, Engine/ts_linear.py)."""
     ops = get_ops()
-    q_len = qkv.shape[0]
+    q_len = qkv.shape[0] if qkv_slab is None else qkv_slab[2]
     n_heads, h_kv, d = dims.local_heads, dims.local_kv_heads, dims.head_dim
     k_layer, v_layer = kv_cache.k_cache[layer_idx, 0], kv_cache.v_cache[layer_idx, 0]
-    attn = torch.empty(ops.frag_shape(q_len, n_heads * d) if out_frag else (q_len, n_heads * d), dtype=qkv.dtype,
-                       device=qkv.device)
+    dt, dev = k_layer.dtype, k_layer.device
+    attn = torch.empty(ops.frag_shape(q_len, n_heads * d) if out_frag else (q_len, n_heads * d), dtype=dt, device=dev)
     scale = 1.0 / math.sqrt(d)
     frag_kw = dict(out_frag=True) if out_frag else {}
-    if tree is not None and tree.contiguous_slots and FUSE_ROPE_ATTENTION and not out_frag:
+    if tree is not None and tree.contiguous_slots and FUSE_ROPE_ATTENTION and not out_frag and qkv_slab is None:
         # one launch: RoPE of q and the new k, KV slot write, tree attention
         ops.rope_tree_attention(qkv, k_layer, v_layer, cos, sin, position_ids, attn, n_heads, h_kv, d, tree.kv_len,
                                 scale, tree.q_slot0, tree.gt, tree.n_tree, tree.bitmask, ctx=tree.ctx)
         return attn
-    q_rot = torch.empty((n_heads, q_len, d), dtype=qkv.dtype, device=qkv.device)
-    ops.rope_kv_write(qkv, q_rot, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d)
+    q_rot = torch.empty((n_heads, q_len, d), dtype=dt, device=dev)
+    if qkv_slab is not None:
+        ops.rope_kv_write_slabs(qkv_slab[0], qkv_slab[1], (n_heads + 2 * h_kv) * d, q_rot, k_layer, v_layer, cos, sin,
+                                position_ids, storage_ids, n_heads, h_kv, d)
+    else:
+        ops.rope_kv_write(qkv, q_rot, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d)
     if tree is not None:
         ops.tree_attention(q_rot, k_layer, v_layer, attn, tree.kv_len, scale, q_slot0=tree.q_slot0, gt=tree.gt,
                            n_tree=tree.n_tree, bitmask=tree.bitmask, ctx=tree.ctx, **frag_kw)

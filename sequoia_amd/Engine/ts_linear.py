@@ -29,7 +29,7 @@ from ..ops import get_ops
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLAN_FILE = os.path.join(_PKG, "ts_plans_gfx950.json")
-MAX_ROWS = 128
+MAX_ROWS = 144
 ENABLED = os.environ.get("SEQUOIA_TS_LINEAR", "1") != "0"
 
 _SHIPPED = None
@@ -50,14 +50,15 @@ def plan_key(n_out: int, k: int, silu: bool, mtp: int) -> str:
     return f"{n_out}x{k}{'s' if silu else ''}@{mtp}"
 
 
-SPLITTABLE = ("o", "down")          # projections whose consumer is the residual add + RMSNorm (reads the slabs)
+SPLITTABLE = ("qkv", "o", "down")   # projections whose consumer reads split-K slabs: RoPE + KV write (qkv), the residual
+#                                     add + RMSNorm (o, down)
 MAX_SPLITS = 8
 
 
 def candidates(n_out: int, k: int, silu: bool, m: int, allow_split: bool = False):
     """(tiles, splits) launch shapes worth timing for one projection."""
     units = n_out // 16
-    max_u = 3 if silu else 4
+    max_u = 3 if silu else (6 if m > 64 else 4)
     ksteps = k // 32
     out = []
     tiles_opts = {(units + u - 1) // u for u in range(1, max_u + 1)}
@@ -274,9 +275,13 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
             ops.embed_rmsnorm(ids, W.embed, lw.ln1, x, h, eps, out_frag=want)
         else:
             h = norm_into(pending, lw.ln1, plan["qkv"] is not None)
-        qkv = project("qkv", li, h)[1]
-        attn = attention_core(qkv, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
-                              out_frag=plan["o"] is not None)
+        qkv = project("qkv", li, h)
+        if qkv[0] == "slab":
+            attn = attention_core(None, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
+                                  out_frag=plan["o"] is not None, qkv_slab=(slab, qkv[1], q_len))
+        else:
+            attn = attention_core(qkv[1], li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
+                                  out_frag=plan["o"] is not None)
         pending = project("o", li, attn)
         h = norm_into(pending, lw.ln2, plan["gate_up"] is not None)
         down_ts = plan["down"] is not None

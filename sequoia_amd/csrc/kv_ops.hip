@@ -243,10 +243,30 @@ extern "C" int sq_kv_clear_f16(void* k_cache, void* v_cache, int n_layers, int h
 // chunk c covers the 8 halves [8c, 8c+8) of the first half and the matching 8 of the second half
 // (rotate_half pairs element e with e + D/2).  fp16 rounding after every op, like the reference's
 // fp16 tensor expression (q * cos) + (rotate_half(q) * sin) (Engine/offload_engine.py:63-66).
-__global__ void rope_kv_write_kernel(const half_t* qkv, int qkv_stride, half_t* q_out, half_t* k_layer,
-                                     half_t* v_layer, const half_t* cos_tab, const half_t* sin_tab,
+// SLAB: the packed q | k | v rows arrive as the split-K partials of the tall-skinny projection (fp32 [splits][q_len][stride],
+// csrc/ts_linear.hip): a value is the sum of its partials in split order, rounded to fp16 -- what the projection itself
+// would have written -- so the projection needs no pass of its own over its output.
+template <bool SLAB>
+__device__ __forceinline__ half8 rope_src8(const half_t* qkv, const float* slab, int splits, size_t split_stride, size_t off) {
+    if (!SLAB) return *(const half8*)(qkv + off);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) {
+        const floatx4 a = *(const floatx4*)(slab + s * split_stride + off), b = *(const floatx4*)(slab + s * split_stride + off + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+    return o;
+}
+
+template <bool SLAB>
+__global__ void rope_kv_write_kernel(const half_t* qkv, const float* slab, int splits, int qkv_stride, half_t* q_out,
+                                     half_t* k_layer, half_t* v_layer, const half_t* cos_tab, const half_t* sin_tab,
                                      const int64_t* position_ids, const int64_t* storage_ids, int q_len, int n_heads,
                                      int h_kv, int d, int m) {
+    const size_t split_stride = (size_t)q_len * qkv_stride;
     const int i = blockIdx.x;
     const int half_d = d >> 1;
     const int chunks = half_d >> 3;            // 16-byte chunks in the first half of a head row
@@ -254,18 +274,18 @@ __global__ void rope_kv_write_kernel(const half_t* qkv, int qkv_stride, half_t* 
     const int hj = idx / chunks;               // head index in the packed q | k | v row
     const int c = idx - hj * chunks;           // chunk of 8 inside the first half
     if (hj >= n_heads + 2 * h_kv) return;
-    const half_t* src = qkv + (size_t)i * qkv_stride + (size_t)hj * d;
+    const size_t src = (size_t)i * qkv_stride + (size_t)hj * d;
     const int64_t slot = storage_ids[i];
     if (hj >= n_heads + h_kv) {                // V: plain copy into the slot
         if (slot < 0 || slot >= m) return;
         half_t* dst = v_layer + ((size_t)(hj - n_heads - h_kv) * m + slot) * d;
-        *(u32x4*)(dst + c * 8) = *(const u32x4*)(src + c * 8);
-        *(u32x4*)(dst + half_d + c * 8) = *(const u32x4*)(src + half_d + c * 8);
+        *(half8*)(dst + c * 8) = rope_src8<SLAB>(qkv, slab, splits, split_stride, src + c * 8);
+        *(half8*)(dst + half_d + c * 8) = rope_src8<SLAB>(qkv, slab, splits, split_stride, src + half_d + c * 8);
         return;
     }
     const int64_t pos = position_ids[i];
-    const half8 x1 = *(const half8*)(src + c * 8);
-    const half8 x2 = *(const half8*)(src + half_d + c * 8);
+    const half8 x1 = rope_src8<SLAB>(qkv, slab, splits, split_stride, src + c * 8);
+    const half8 x2 = rope_src8<SLAB>(qkv, slab, splits, split_stride, src + half_d + c * 8);
     const half8 c1 = *(const half8*)(cos_tab + (size_t)pos * d + c * 8);
     const half8 c2 = *(const half8*)(cos_tab + (size_t)pos * d + half_d + c * 8);
     const half8 s1 = *(const half8*)(sin_tab + (size_t)pos * d + c * 8);
@@ -292,18 +312,40 @@ __global__ void rope_kv_write_kernel(const half_t* qkv, int qkv_stride, half_t* 
     *(half8*)(dst + half_d + c * 8) = o2;
 }
 
-extern "C" int sq_rope_kv_write_f16(const void* qkv, int qkv_stride, void* q_out, void* k_layer, void* v_layer,
-                                    const void* cos_tab, const void* sin_tab, const int64_t* d_position_ids,
-                                    const int64_t* d_storage_ids, int q_len, int n_heads, int h_kv, int d, int m,
-                                    void* stream) {
-    if (!qkv || !q_out || !k_layer || !v_layer || !cos_tab || !sin_tab || !d_position_ids || !d_storage_ids) return SQ_EINVAL;
+static int rope_launch(const void* qkv, const float* slab, int splits, int qkv_stride, void* q_out, void* k_layer,
+                       void* v_layer, const void* cos_tab, const void* sin_tab, const int64_t* d_position_ids,
+                       const int64_t* d_storage_ids, int q_len, int n_heads, int h_kv, int d, int m, void* stream) {
+    if (!q_out || !k_layer || !v_layer || !cos_tab || !sin_tab || !d_position_ids || !d_storage_ids) return SQ_EINVAL;
     if (q_len < 0 || n_heads <= 0 || h_kv <= 0 || m <= 0 || qkv_stride < (n_heads + 2 * h_kv) * d) return SQ_EINVAL;
     if (d <= 0 || (d & 15) || d > 1024 || (qkv_stride & 7)) return SQ_EUNSUPPORTED;
     if (q_len == 0) return SQ_OK;
     const int work = (n_heads + 2 * h_kv) * (d >> 4);
-    hipLaunchKernelGGL(rope_kv_write_kernel, dim3(q_len, (work + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)qkv, qkv_stride, (half_t*)q_out, (half_t*)k_layer, (half_t*)v_layer,
-                       (const half_t*)cos_tab, (const half_t*)sin_tab, d_position_ids, d_storage_ids, q_len, n_heads,
-                       h_kv, d, m);
+    const dim3 g(q_len, (work + 255) / 256), b(256);
+    if (slab)
+        hipLaunchKernelGGL(rope_kv_write_kernel<true>, g, b, 0, (hipStream_t)stream, (const half_t*)nullptr, slab, splits,
+                           qkv_stride, (half_t*)q_out, (half_t*)k_layer, (half_t*)v_layer, (const half_t*)cos_tab,
+                           (const half_t*)sin_tab, d_position_ids, d_storage_ids, q_len, n_heads, h_kv, d, m);
+    else
+        hipLaunchKernelGGL(rope_kv_write_kernel<false>, g, b, 0, (hipStream_t)stream, (const half_t*)qkv, (const float*)nullptr,
+                           0, qkv_stride, (half_t*)q_out, (half_t*)k_layer, (half_t*)v_layer, (const half_t*)cos_tab,
+                           (const half_t*)sin_tab, d_position_ids, d_storage_ids, q_len, n_heads, h_kv, d, m);
     return sq_check_launch();
+}
+
+extern "C" int sq_rope_kv_write_f16(const void* qkv, int qkv_stride, void* q_out, void* k_layer, void* v_layer,
+                                    const void* cos_tab, const void* sin_tab, const int64_t* d_position_ids,
+                                    const int64_t* d_storage_ids, int q_len, int n_heads, int h_kv, int d, int m,
+                                    void* stream) {
+    if (!qkv) return SQ_EINVAL;
+    return rope_launch(qkv, nullptr, 0, qkv_stride, q_out, k_layer, v_layer, cos_tab, sin_tab, d_position_ids, d_storage_ids,
+                       q_len, n_heads, h_kv, d, m, stream);
+}
+
+extern "C" int sq_rope_kv_write_slabs_f16(const float* qkv_slab, int splits, int qkv_stride, void* q_out, void* k_layer,
+                                          void* v_layer, const void* cos_tab, const void* sin_tab,
+                                          const int64_t* d_position_ids, const int64_t* d_storage_ids, int q_len, int n_heads,
+                                          int h_kv, int d, int m, void* stream) {
+    if (!qkv_slab || splits < 1 || ((uintptr_t)qkv_slab & 15)) return SQ_EINVAL;
+    return rope_launch(nullptr, qkv_slab, splits, qkv_stride, q_out, k_layer, v_layer, cos_tab, sin_tab, d_position_ids,
+                       d_storage_ids, q_len, n_heads, h_kv, d, m, stream);
 }

@@ -1,4 +1,4 @@
-// Tall-skinny linear layers of the tree forwards: out[M, N] = A[M, K] . W[N, K]^T for M <= 128 rows
+// Tall-skinny linear layers of the tree forwards: out[M, N] = A[M, K] . W[N, K]^T for M <= 144 rows
 // (M = the nodes of one speculation tree / tree level), fp16 in, fp32 accumulate, fp16 out.
 //
 // The regime: every weight is used by <= 128 rows, so the layer is an HBM stream of W (7B: 13 GB per
@@ -29,10 +29,11 @@
 //     h(h(silu(h(g))) * h(u)), the rounding points of LlamaMLP_FI, Engine/Llama_modules.py:271); the output
 //     is row-major or fragment-major (when it feeds the next tall-skinny layer).
 #include "common.h"
+#include <stdlib.h>
 
 #define TS_WAVES 4
 #define TS_THREADS (TS_WAVES * 64)
-#define TS_MAXM 128
+#define TS_MAXM 144              // 9 row tiles: the 129-node 64x2 tree of the 70B configuration
 
 struct TsParams {
     const half_t* a;      // fragment-major activations [K/32][mtp][64][8]
@@ -41,6 +42,7 @@ struct TsParams {
     half_t* out;          // [M][ldo] row-major, or fragment-major [n_out/32][mtp][64][8]   (splits == 1)
     float* slab;          // [splits][M][n_out] fp32                                         (splits > 1)
     int m, mtp, n_out, k, ldo, splits, tiles, units, out_frag;
+    int dbg;              // experiment switches (SQ_TS_DEBUG): 1 = activations from one k-step (L1 hits), 2 = weights likewise
 };
 
 // row tiles per merge pass: 4 wave images of [16 MH][16 NT + 4] fp32 must fit 150 KB of LDS
@@ -80,7 +82,8 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) aoff[mt] = (uint32_t)min(mt, P.mtp - 1) * 1024u + (uint32_t)lane * 16u;
-    const uint32_t a_step = (uint32_t)P.mtp * 1024u;
+    const uint32_t a_step = (P.dbg & 1) ? 0u : (uint32_t)P.mtp * 1024u;
+    const uint32_t w_shift = (P.dbg & 2) ? 31u : 10u;
     const char* wbase = (const char*)P.w;
     const char* abase = (const char*)P.a;
 
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
 #define TS_KS(I) ({ int i_ = (I) + rot; i_ = i_ >= nst ? i_ - nst : i_; i_ = i_ >= nst ? i_ - nst : i_; ks0 + i_; })
 #define TS_LOAD(d, KS)                                                                                 \
     {                                                                                                  \
-        const uint32_t kw_ = (uint32_t)(KS) << 10, ka_ = (uint32_t)(KS) * a_step;                      \
+        const uint32_t kw_ = ((uint32_t)(KS) << w_shift) & 0x7fffffffu, ka_ = (uint32_t)(KS) * a_step;                      \
         _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                 \
             wr[d][t] = __builtin_nontemporal_load((const half8*)(wbase + (woff[t] + kw_)));            \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ar[d][mt] = *(const half8*)(abase + (aoff[mt] + ka_)); \
@@ -119,8 +122,8 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
         for (int it = 0; it < nfull; ++it, i += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                TS_MMA(d);
-                TS_LOAD(d, TS_KS(min(i + D + d, nst - 1)));   // refill the stage just consumed (clamped at the end)
+                if (!(P.dbg & 4)) TS_MMA(d);
+                if (!(P.dbg & 8)) TS_LOAD(d, TS_KS(min(i + D + d, nst - 1)));   // refill the stage just consumed (clamped at the end)
                 __builtin_amdgcn_sched_barrier(0);           // keep the stages in ring order (no cross-stage MFMA interleave)
             }
         }
@@ -213,7 +216,7 @@ static void ts_go(const TsParams& P, hipStream_t st) {
     // wave-private LDS ring, hand-counted waits: 27.6 vs 29.6 us on the 128-row qkv, 64 vs 62 us on gate_up) are no
     // faster -- the stream is bound by the CU's memory ingest (~14 B/clk/CU for weights + activations together),
     // not by bytes in flight or by the VGPR return path.
-    constexpr int D = (MT * NT > 24) ? 3 : 4;
+    constexpr int D = (MT * NT > 48) ? 2 : ((MT * NT > 24) ? 3 : 4);     // 8 x 8 accumulator tiles: 256 registers, ring of 2
     const size_t lds = (size_t)TS_WAVES * ts_merge_tiles(MT, NT) * 16 * (NT * 16 + 4) * sizeof(float);
     auto kern = ts_linear_kernel<MT, NT, D, SILU>;
     static bool attr_done[16] = {};          // the attribute is per (function, device)
@@ -238,6 +241,8 @@ static int ts_dispatch(const TsParams& P, int silu, int nt, hipStream_t st) {
     if (nt <= 2) ts_go<MT, 2, false>(P, st);
     else if (nt <= 3) ts_go<MT, 3, false>(P, st);
     else if (nt <= 4) ts_go<MT, 4, false>(P, st);
+    else if (nt <= 6) ts_go<MT, 6, false>(P, st);
+    else if (nt <= 8) ts_go<MT, 8, false>(P, st);
     else return SQ_EUNSUPPORTED;
     return SQ_OK;
 }
@@ -256,6 +261,7 @@ extern "C" int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const vo
     P.slab = (float*)slab;
     P.m = m; P.mtp = (m + 15) / 16; P.n_out = n_out; P.k = k; P.ldo = ldo; P.splits = splits; P.out_frag = out_frag;
     P.units = n_out / 16;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SQ_TS_DEBUG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
     P.tiles = tiles > P.units ? P.units : tiles;
     if (splits > 1) {
         if (silu || res || out_frag) return SQ_EUNSUPPORTED;   // the slab consumer applies the epilogue
@@ -272,7 +278,8 @@ extern "C" int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const vo
     else if (mt == 3) rc = ts_dispatch<3>(P, silu, nt, st);
     else if (mt == 4) rc = ts_dispatch<4>(P, silu, nt, st);
     else if (mt <= 6) rc = ts_dispatch<6>(P, silu, nt, st);
-    else rc = ts_dispatch<8>(P, silu, nt, st);
+    else if (mt <= 8) rc = ts_dispatch<8>(P, silu, nt, st);
+    else rc = ts_dispatch<9>(P, silu, nt, st);
     if (rc != SQ_OK) return rc;
     return sq_check_launch();
 }

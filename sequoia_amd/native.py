@@ -35,6 +35,7 @@ PROTOTYPES = {
     "sq_kv_compact_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sq_kv_clear_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_rope_kv_write_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sq_rope_kv_write_slabs_f16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_tree_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _i, _i, _i,
                                    _vp, _i, _vp, _vp]),
     "sq_rope_tree_attention_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i,

@@ -98,6 +98,20 @@ class HipOps:
                                             storage_ids.data_ptr(), qkv.shape[0], n_heads, h_kv, d, m, self._stream()),
               "sq_rope_kv_write_f16")
 
+    def rope_kv_write_slabs(self, slab, splits, n_cols, q_out, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads,
+                            h_kv, d):
+        """rope_kv_write on the split-K partials [splits][q_len][n_cols] (fp32) of the qkv projection."""
+        _need(slab, torch.float32, "slab")
+        _need(q_out, torch.float16, "q_out"); _need(k_layer, torch.float16, "k_layer"); _need(v_layer, torch.float16, "v_layer")
+        _need(cos, torch.float16, "cos"); _need(sin, torch.float16, "sin")
+        _need(position_ids, torch.int64, "position_ids"); _need(storage_ids, torch.int64, "storage_ids")
+        q_len, m = position_ids.numel(), k_layer.shape[-2]
+        assert slab.numel() >= splits * q_len * n_cols
+        check(self.lib.sq_rope_kv_write_slabs_f16(slab.data_ptr(), int(splits), int(n_cols), q_out.data_ptr(), k_layer.data_ptr(),
+                                                  v_layer.data_ptr(), cos.data_ptr(), sin.data_ptr(), position_ids.data_ptr(),
+                                                  storage_ids.data_ptr(), q_len, n_heads, h_kv, d, m, self._stream()),
+              "sq_rope_kv_write_slabs_f16")
+
     def store_i32(self, dst, values):
         _need(dst, torch.int32, "dst")
         v = list(values) + [0] * (4 - len(values))

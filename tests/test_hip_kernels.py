@@ -468,3 +468,31 @@ def test_fused_rope_attention_equals_two_kernel_path(ops, H, Hkv, D, M, gt, n, q
     ops.rope_tree_attention(qkv, kb, vb, dcos, dsin, pos, out_b, H, Hkv, D, kv_len, scale, q_slot0, gt, n, bm)
     assert torch.equal(ka, kb) and torch.equal(va, vb)
     assert torch.equal(out_a, out_b)
+
+
+@pytest.mark.parametrize("H,Hkv,D,q,splits", [(4, 4, 64, 7, 2), (32, 32, 128, 128, 2), (8, 1, 128, 129, 3)])
+def test_rope_kv_write_from_split_k_slabs(ops, H, Hkv, D, q, splits):
+    """sq_rope_kv_write_slabs_f16 == sq_rope_kv_write_f16 on h(sum of the partials in split order), bit for bit."""
+    rng = np.random.RandomState(H + q)
+    M = 256
+    n_cols = (H + 2 * Hkv) * D
+    parts = (rng.randn(splits, q, n_cols) * 0.7).astype(np.float32)
+    acc = np.zeros((q, n_cols), np.float32)
+    for s in range(splits):
+        acc = acc + parts[s]
+    qkv = acc.astype(np.float16)
+    cos, sin = O.rope_tables(D, 512)
+    pos = rng.randint(0, 512, size=q).astype(np.int64)
+    sid = rng.permutation(M)[:q].astype(np.int64)
+    k0 = rng.randn(Hkv, M, D).astype(np.float16); v0 = rng.randn(Hkv, M, D).astype(np.float16)
+    outs = []
+    for use_slab in (False, True):
+        dk, dv = dev(k0), dev(v0)
+        dq = torch.empty(H, q, D, dtype=torch.float16, device=DEV)
+        if use_slab:
+            ops.rope_kv_write_slabs(dev(parts), splits, n_cols, dq, dk, dv, dev(cos), dev(sin), dev(pos), dev(sid), H, Hkv, D)
+        else:
+            ops.rope_kv_write(dev(qkv), dq, dk, dv, dev(cos), dev(sin), dev(pos), dev(sid), H, Hkv, D)
+        outs.append((dq.cpu(), dk.cpu(), dv.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

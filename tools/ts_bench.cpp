@@ -58,11 +58,11 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(dr, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
             // (tiles, splits) candidates
             std::vector<std::pair<int, int>> cands;
-            const int max_u = sh.silu ? 3 : 4;
-            for (int upt = 1; upt <= max_u; ++upt)
+            const int max_u = sh.silu ? 3 : 8;
+            for (int upt = (getenv("TS_MIN_U") ? atoi(getenv("TS_MIN_U")) : 1); upt <= max_u; ++upt)
                 for (int sp : {1, 2, 3, 4, 6, 8}) {
                     const int tiles = (units + upt - 1) / upt;
-                    if (sp > 1 && (sh.silu || sh.n_out > 8192)) continue;
+                    if (sp > 1 && (sh.silu || sh.n_out > 16384)) continue;
                     if (sp == 1 && sh.res == 0 && false) continue;
                     const long wgs = (long)tiles * sp;
                     if (wgs < 128 || wgs > 2100) continue;
