@@ -213,6 +213,31 @@ def spawn_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def tp_extra(n: int, args) -> dict:
+    """Configuration E beside the replica headline when several GPUs are available: the 70B target tensor-parallel over
+    the same N GPUs (RCCL all-reduce over xGMI), as a CHILD job with a timeout -- a stuck collective cannot take the
+    headline line with it.  Returns the child's JSON line (trimmed) or an error record."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--config", "E", "--steps", str(min(args.steps, 24)),
+           "--warmup", "2", "--no-cpu-baseline", "--no-autoregressive", "--no-tuned-growmap", "--no-tp-extra", "--sync-loop"]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                        "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                        "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
+    env["SEQUOIA_TS_EXCLUSIVE"] = "1"          # one copy of the 70B shard per rank
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=int(os.environ.get("SEQUOIA_TP_EXTRA_TIMEOUT", "420")),
+                             env=env)
+    except subprocess.TimeoutExpired:
+        return dict(error="timeout")
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return dict(error=f"rc {out.returncode}", stderr=out.stderr[-400:])
+    d = json.loads(lines[-1])
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "mean_accepted_len", "rccl_ranks", "config")
+    return {k: d[k] for k in keep if k in d}
+
+
 def selftest(args, world, rank):
     """Launcher / rendezvous / aggregation check without a model: K timed no-op steps per rank, the same barrier +
     max-over-ranks timing and the same JSON assembly as the real run (used by the CPU test of the N > 1 path)."""
@@ -257,6 +282,8 @@ def main():
     ap.add_argument("--sync-loop", action="store_true",
                     help="drive every step from the host (reference API: construct_grow_map + verify with one result read "
                          "per step) instead of the device-driven whole-step graphs")
+    ap.add_argument("--no-tp-extra", action="store_true",
+                    help="N > 1: skip the secondary run of configuration E (70B target tensor-parallel over the N GPUs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--selftest", action="store_true", help="launcher / aggregation check without a model (CPU-runnable)")
     args = ap.parse_args()
@@ -399,9 +426,17 @@ def main():
                     roofline=roof, kernels=kernels, host_driven_loop=host_loop, mi355x_growmap=tuned,
                     autoregressive_baseline=autoreg,
                     cpu_baseline=cpu)
-        print(json.dumps(line))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and not tp_mode and not args.no_tp_extra:
+            # the other ranks are exiting: their GPUs are free for the tensor-parallel child job
+            del loop, draft, target
+            torch.cuda.empty_cache()
+            time.sleep(3.0)
+            line["tp_70b"] = tp_extra(world, args)
+        print(json.dumps(line))
 
 
 if __name__ == "__main__":

@@ -270,7 +270,9 @@ class _LlamaForCausalLM:
         self.cos, self.sin = rope_tables(self.dims.head_dim, self.dims.max_position_embeddings, self.dims.rope_theta,
                                          self.device, self.dtype)
         # tall-skinny projections for tree forwards (<= 128 rows): fragment-major weight stream, Engine/ts_linear.py
-        self.ts = TsLinearSet(weights, self.dims) if TsLinearSet.supported(weights, self.dims, reduce_fn) else None
+        self.ts = TsLinearSet(weights, self.dims) if TsLinearSet.supported(weights, self.dims) else None
+        if self.ts is not None and os.environ.get("SEQUOIA_TS_EXCLUSIVE", "0") == "1":
+            self.ts.make_exclusive()
         self.reduce_fn = reduce_fn                  # TP all-reduce hook (None on one GPU)
         self.gather_logits_fn = gather_logits_fn    # TP vocab all-gather hook
 
@@ -312,9 +314,11 @@ class _LlamaForCausalLM:
                                      f"{tuple(attention_mask.size())}")
             if dense.dtype != self.dtype:
                 dense = dense.to(self.dtype)
-        # (reduce_fn / gather_logits_fn are attached after construction by the TP engine: check at call time)
-        if (self.ts is not None and q_len <= TS_MAX_ROWS and self.reduce_fn is None and self.gather_logits_fn is None):
+        # tree forwards (and tensor-parallel shards: the hooks are applied inside forward_ts) on the tall-skinny path
+        if self.ts is not None and q_len <= TS_MAX_ROWS:
             return forward_ts(self, self.ts, input_ids[0], q_len, pos, storage_ids, dense, tree, kv_cache)
+        if self.ts is not None and self.ts.exclusive:
+            return self._forward_chunked(input_ids, q_len, pos, storage_ids, dense, tree, kv_cache)
         x = F.embedding(input_ids[0], W.embed)                      # [q, hidden]
         hbuf = torch.empty_like(x)
         pending = None                                               # branch output not yet added to x
@@ -336,6 +340,26 @@ class _LlamaForCausalLM:
         if self.gather_logits_fn is not None:
             logits = self.gather_logits_fn(logits)
         return logits.unsqueeze(0)
+
+    def _forward_chunked(self, input_ids, q_len, pos, storage_ids, dense, tree, kv_cache):
+        """More than MAX_ROWS new tokens when the fragment-major images are the only copy of the weights (exclusive
+        mode): the rows run as consecutive chunks of <= MAX_ROWS.  A chunk's queries see the earlier chunks through the
+        KV cache (causal prefix / tree mask by slot), so the result equals the one-pass forward up to accumulation order."""
+        outs = []
+        for r0 in range(0, q_len, TS_MAX_ROWS):
+            r1 = min(q_len, r0 + TS_MAX_ROWS)
+            sub_tree, sub_dense = None, None
+            if tree is not None:
+                if tree.ctx is not None:
+                    raise RuntimeError("chunked forwards cannot replay from a captured context block")
+                sub_tree = TreeContext(q_slot0=tree.q_slot0 + r0, gt=tree.gt, n_tree=tree.n_tree, bitmask=tree.bitmask,
+                                       kv_len=tree.q_slot0 + r1 if tree.contiguous_slots else tree.kv_len,
+                                       contiguous_slots=tree.contiguous_slots)
+            else:
+                sub_dense = dense[r0:r1]
+            outs.append(forward_ts(self, self.ts, input_ids[0, r0:r1], r1 - r0, pos[r0:r1], storage_ids[r0:r1], sub_dense,
+                                   sub_tree, kv_cache)[0])
+        return torch.cat(outs, dim=0).unsqueeze(0)
 
     __call__ = forward
 

@@ -15,13 +15,14 @@ decisions and no broadcast is needed.
 """
 from __future__ import annotations
 
-from typing import Optional
+import os
 
 import torch
 import torch.distributed as dist
 
-from .Engine import InferenceEngineTG
-from .Llama_modules import TreeContext
+from .Engine import GraphInferenceEngineTG, InferenceEngineTG
+
+FORCE_HOOKS = os.environ.get("SEQUOIA_TP_FORCE_HOOKS", "0") == "1"
 
 
 class _TPInner(InferenceEngineTG):
@@ -29,22 +30,37 @@ class _TPInner(InferenceEngineTG):
         super().__init__(max_length, model_name_or_path, dtype, device, tp_world=world, tp_rank=rank)
         self.group = group
         self.world = world
-        if world > 1:
+        self.collectives = 0                 # all-reduce / all-gather calls issued (eager count; tests)
+        if world > 1 or FORCE_HOOKS:
+            # (world 1 with SEQUOIA_TP_FORCE_HOOKS=1: a single-GPU box still runs every hook, RCCL call and capture)
             self.model.reduce_fn = self._all_reduce
             self.model.gather_logits_fn = self._gather_vocab
 
     def _all_reduce(self, x):
-        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        self.collectives += 1
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x
 
     def _gather_vocab(self, logits):
+        """[q, V / world] per rank (rank r owns vocabulary rows [r V / world, (r + 1) V / world)) -> [q, V]."""
+        self.collectives += 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return logits
+        q, v = logits.shape
+        logits = logits.contiguous()
+        if logits.device.type == "cuda":
+            out = torch.empty((self.world, q, v), dtype=logits.dtype, device=logits.device)
+            dist.all_gather_into_tensor(out, logits, group=self.group)
+            return out.permute(1, 0, 2).reshape(q, self.world * v)
         parts = [torch.empty_like(logits) for _ in range(self.world)]
-        dist.all_gather(parts, logits.contiguous(), group=self.group)
+        dist.all_gather(parts, logits, group=self.group)
         return torch.cat(parts, dim=-1)
 
 
-class TPEngine:
-    """Same method set as GraphInferenceEngineTG / OffloadEngine."""
+class TPEngine(GraphInferenceEngineTG):
+    """Same method set as GraphInferenceEngineTG / OffloadEngine, including initialize_cuda_graph / graph_inference:
+    the all-reduces are captured into the forward's hipGraph (RCCL calls are stream-ordered)."""
 
     def __init__(self, max_length: int, model_name_or_path, dtype=torch.float16, device="cuda:0",
                  process_group=None) -> None:
@@ -55,25 +71,7 @@ class TPEngine:
         else:
             self.world, self.rank = 1, 0
         self.engine = _TPInner(max_length, model_name_or_path, dtype, device, process_group, self.world, self.rank)
-
-    def clear_kv(self):
-        self.engine.clear_kv()
-
-    def initialize_kv(self, k_cache, v_cache, kv_len: int):
-        self.engine.initialize_kv(k_cache, v_cache, kv_len)
-
-    def get_kv_cache(self, in_place=False):
-        return self.engine.get_kv_cache(in_place=in_place)
-
-    def gather_kv(self, indices):
-        self.engine.gather_kv(indices)
-
-    def set_kv_len(self, kv_len: int):
-        self.engine.set_kv_len(kv_len)
-
-    @torch.no_grad()
-    def inference(self, input_ids: torch.LongTensor, storage_ids: torch.LongTensor,
-                  position_ids: Optional[torch.LongTensor] = None, attn_mask: Optional[torch.Tensor] = None,
-                  tree: Optional[TreeContext] = None):
-        return self.engine.model_run(input_ids=input_ids, storage_ids=storage_ids, attention_mask=attn_mask,
-                                     position_ids=position_ids, tree=tree)
+        self.callables = {}
+        self.tree_callables = {}
+        self.requested_graph_lengths = set()
+        self.mempool = None

@@ -92,14 +92,19 @@ class TsLinearSet:
             "down": (d.hidden_size, weights.layers[0].w_down.shape[1], False),
             "lm_head": (weights.lm_head.shape[0], d.hidden_size, False),
         }
+        # exclusive: the fragment-major images are the ONLY copy of the layer projections (the row-major nn.Linear
+        # layout is released after the repack: 70B on few GPUs); forwards of more than MAX_ROWS rows then run as row chunks
+        self.exclusive = False
+        self._zero_rows = torch.zeros((MAX_ROWS, d.hidden_size), dtype=torch.float16, device=self.device)
         # split-K partials [splits][rows][n_out] fp32: one buffer for the model's life (captured graphs hold it)
         self._slab = torch.empty(MAX_SPLITS * MAX_ROWS * max(self.shapes[n][0] for n in SPLITTABLE), dtype=torch.float32,
                                  device=self.device)
 
     @staticmethod
-    def supported(weights, dims, reduce_fn) -> bool:
-        if (not ENABLED or reduce_fn is not None or torch.device(weights.device).type != "cuda"
-                or weights.dtype != torch.float16):
+    def supported(weights, dims, reduce_fn=None) -> bool:
+        """Tensor-parallel shards qualify too: the all-reduce of a row-parallel projection is applied between the
+        projection and the residual add (forward_ts)."""
+        if not ENABLED or torch.device(weights.device).type != "cuda" or weights.dtype != torch.float16:
             return False
         inter = weights.layers[0].w_down.shape[1]
         hd = dims.local_heads * dims.head_dim
@@ -113,7 +118,10 @@ class TsLinearSet:
         if name == "lm_head":
             return self.W.lm_head
         lw = self.W.layers[li]
-        return {"qkv": lw.wqkv, "o": lw.wo, "gate_up": lw.w_gate_up, "down": lw.w_down}[name]
+        w = {"qkv": lw.wqkv, "o": lw.wo, "gate_up": lw.w_gate_up, "down": lw.w_down}[name]
+        if w is None:
+            raise RuntimeError(f"row-major {name} weights were released (exclusive tall-skinny mode)")
+        return w
 
     def frag(self, name, li=0):
         key = (name, 0 if name == "lm_head" else li)
@@ -122,6 +130,31 @@ class TsLinearSet:
             t = get_ops().repack_weight(self._row_major(name, li))
             self._frag[key] = t
         return t
+
+    def make_exclusive(self):
+        """Repack every layer projection now and release the row-major copies (layer by layer: peak = one extra layer)."""
+        if self.exclusive:
+            return
+        for li, lw in enumerate(self.W.layers):
+            for name, attr in (("qkv", "wqkv"), ("o", "wo"), ("gate_up", "w_gate_up"), ("down", "w_down")):
+                self.frag(name, li)
+                setattr(lw, attr, None)
+        self.exclusive = True
+        self._plans.clear()
+        torch.cuda.empty_cache()
+
+    def default_plan(self, name, q_len):
+        """A launch shape that always works (exclusive mode cannot fall back to PyTorch's GEMM): about one workgroup per
+        compute unit, the widest column tiles the row count allows."""
+        n_out, k, silu = self.shapes[name]
+        units = n_out // 16
+        max_u = 3 if silu else (6 if q_len > 64 else 4)
+        tiles = max((units + max_u - 1) // max_u, min(units, 256))
+        splits = 1
+        if name in SPLITTABLE:
+            while tiles * splits < 192 and splits < MAX_SPLITS and (k // 32) >= (splits + 1) * 8:
+                splits += 1
+        return (tiles, splits)
 
     def _images_fit(self, name) -> bool:
         """A second copy of this projection's weights must leave the device comfortable (70B on one GPU does not)."""
@@ -142,7 +175,10 @@ class TsLinearSet:
                 n_out, k, silu = self.shapes[name]
                 rec = shipped_plans().get(plan_key(n_out, k, silu, mtp))
                 have_images = (name, 0) in self._frag
-                if capturing and (rec is None or not have_images):
+                if self.exclusive and name != "lm_head":
+                    if rec is None or rec == "torch":
+                        rec = self.default_plan(name, q_len)
+                elif capturing and (rec is None or not have_images):
                     rec = "torch"          # no timing, no allocation, no repack inside a capture (the eager warm-ups
                     #                        of a graph runner come first and cache the real plan)
                 elif rec != "torch" and not have_images and not self._images_fit(name):
@@ -207,7 +243,7 @@ class TsLinearSet:
             def ts_fn(li, tiles=tiles, splits=splits, slab=slab):
                 ops.linear_ts(xf, self.frag(name, li), q_len, n_out, k, out=out, silu=silu, tiles=tiles, splits=splits,
                               slab=slab)
-            for li in range(n_layers):
+            for li in range(n_layers):                       # weight images exist before anything is captured
                 self.frag(name, li)
             t = timeit(ts_fn)
             results[f"{tiles}x{splits}"] = round(t, 2)
@@ -222,8 +258,10 @@ class TsLinearSet:
 
 
 def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree, kv_cache):
-    """Decoder forward of <= 128 tree tokens on the tall-skinny projections.  ids: int64 [q] token ids.
-    Returns logits [1, q, V]."""
+    """Decoder forward of <= MAX_ROWS tree tokens on the tall-skinny projections.  ids: int64 [q] token ids.
+    Returns logits [1, q, V].  Tensor-parallel shards (model.reduce_fn set): the partial output of the row-parallel
+    projections (o_proj, down_proj) is reduced across ranks before the residual add; the vocabulary-parallel logits
+    are gathered at the end (model.gather_logits_fn)."""
     from .Llama_modules import attention_core
     ops = get_ops()
     W, dims = model.weights, model.dims
@@ -237,6 +275,19 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
     vocab = ts.shapes["lm_head"][0]
     fs = ops.frag_shape
     slab = ts._slab
+    reduce_fn, gather_fn = model.reduce_fn, model.gather_logits_fn
+
+    def reduced(pending):
+        """Row-parallel projection under tensor parallelism: this rank's partial product as fp16 rows (split-K slabs
+        are summed first), all-reduced over the ranks."""
+        if reduce_fn is None:
+            return pending
+        if pending[0] == "slab":
+            rows = torch.empty((q_len, hidden), dtype=dt, device=dev)
+            ops.add_rmsnorm_slabs(slab, pending[1], ts._zero_rows[:q_len], rows, None, None, eps)
+        else:
+            rows = pending[1]
+        return ("rows", reduce_fn(rows))
 
     def norm_into(pending, weight, want_frag):
         """Apply the pending branch output (None | ("rows", t) | ("slab", splits)) to the residual stream x,
@@ -282,7 +333,7 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
         else:
             attn = attention_core(qkv[1], li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
                                   out_frag=plan["o"] is not None)
-        pending = project("o", li, attn)
+        pending = reduced(project("o", li, attn))
         h = norm_into(pending, lw.ln2, plan["gate_up"] is not None)
         down_ts = plan["down"] is not None
         act = torch.empty(fs(q_len, inter) if down_ts else (q_len, inter), dtype=dt, device=dev)
@@ -295,7 +346,7 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
                 ops.silu_mul_frag(gu, act, q_len, inter)
             else:
                 ops.silu_mul(gu, act)
-        pending = project("down", li, act)
+        pending = reduced(project("down", li, act))
     h = norm_into(pending, W.norm, plan["lm_head"] is not None)
     kv_cache.note_written(q_len)
     if plan["lm_head"] is not None:
@@ -304,4 +355,6 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
         ops.linear_ts(h, ts.frag("lm_head"), q_len, vocab, hidden, out=logits, tiles=tiles)
     else:
         logits = F.linear(h, W.lm_head)
+    if gather_fn is not None:
+        logits = gather_fn(logits)
     return logits.unsqueeze(0)

@@ -80,7 +80,8 @@ class Loop:
         if use_graphs:
             lens = sorted({lv.total for lv in g.levels} | {1})
             draft.initialize_cuda_graph(lens, tree_bitmask=gdev["bitmask"], n_tree=g.size)
-            if hasattr(target, "initialize_cuda_graph"):
+            # (tensor-parallel target: the verify forward is captured with its RCCL all-reduces only on request)
+            if hasattr(target, "initialize_cuda_graph") and (not cfg.get("tp") or os.environ.get("SEQUOIA_TP_GRAPHS", "0") == "1"):
                 target.initialize_cuda_graph([g.size], tree_bitmask=gdev["bitmask"], n_tree=g.size)
         self.pi = 0
         self.tree = None

@@ -243,10 +243,10 @@ def test_plan_candidates_respect_kernel_limits():
             assert k // 32 >= splits * 8 and (splits == 1 or not silu)
 
 
-def test_tensor_parallel_hooks_disable_the_tall_skinny_path(monkeypatch):
-    """The TP engine attaches its all-reduce / vocab-gather hooks after the model is built; a forward with hooks must
-    stay on the general path (row-parallel partial sums need the reduction between o_proj / down_proj and the add)."""
-    from sequoia_amd.Engine import Llama_model
+def test_tensor_parallel_hooks_run_on_the_tall_skinny_path():
+    """The TP engine attaches its all-reduce / vocab-gather hooks after the model is built; a tree forward with hooks stays
+    on the tall-skinny projections and applies the reduction between o_proj / down_proj and the residual add -- with an
+    identity hook the logits equal the hook-free forward bit for bit."""
     from sequoia_amd.Engine.Engine import GraphInferenceEngine
     from sequoia_amd.Engine.Llama_model import LlamaDims, LlamaWeights
     from sequoia_amd.Engine.Llama_modules import TreeContext
@@ -256,18 +256,18 @@ def test_tensor_parallel_hooks_disable_the_tall_skinny_path(monkeypatch):
     eng = GraphInferenceEngine(max_length=128, model_name_or_path={"weights": W}, dtype=torch.float16, device=DEV)
     model = eng.engine.model
     assert model.ts is not None
-    calls = []
-    model.reduce_fn = lambda t: (calls.append(1), t)[1]
-
-    def boom(*a, **k):
-        raise AssertionError("tall-skinny path taken with TP hooks attached")
-    monkeypatch.setattr(Llama_model, "forward_ts", boom)
     ids = torch.randint(3, 2048, (1, 20), device=DEV)
     ar = torch.arange(20, device=DEV)
     bm = torch.ones((1, 1), dtype=torch.int64, device=DEV)
-    eng.inference(input_ids=ids, storage_ids=ar, position_ids=ar[None], attn_mask=None,
-                  tree=TreeContext(q_slot0=0, gt=20, n_tree=1, bitmask=bm, kv_len=20, contiguous_slots=True))
-    assert len(calls) == 4          # o_proj and down_proj of both layers went through the hook
+    ctx = TreeContext(q_slot0=0, gt=20, n_tree=1, bitmask=bm, kv_len=20, contiguous_slots=True)
+    plain = eng.inference(input_ids=ids, storage_ids=ar, position_ids=ar[None], attn_mask=None, tree=ctx).clone()
+    calls, gathers = [], []
+    model.reduce_fn = lambda t: (calls.append(tuple(t.shape)), t)[1]
+    model.gather_logits_fn = lambda t: (gathers.append(1), t)[1]
+    eng.clear_kv()
+    hooked = eng.inference(input_ids=ids, storage_ids=ar, position_ids=ar[None], attn_mask=None, tree=ctx)
+    assert calls == [(20, 256)] * 4 and len(gathers) == 1     # o_proj and down_proj of both layers, then the logits
+    assert torch.equal(plain, hooked)
 
 
 @pytest.mark.parametrize("rows,hidden,vocab,frag", [(1, 768, 1000, True), (34, 768, 32000, False), (128, 4096, 32000, True), (48, 5120, 500, True)])

@@ -1,9 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r2
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/r2/tests4.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r2/tests4.log
-grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/r2/tests4.log | tail -20
-timeout 600 python bench.py --steps 200 --warmup 8 --no-cpu-baseline > gpurun_out/r2/bench_v2.log 2>&1; tail -1 gpurun_out/r2/bench_v2.log | python -c "
-import sys,json
-d=json.loads(sys.stdin.read())
-print({k:d[k] for k in ('value','ms_per_step','mean_accepted_len')}, d['host_driven_loop'], d['mi355x_growmap'], d['autoregressive_baseline'])
-print(d['roofline']); print({k:round(v['avg_us'],1) for k,v in d['kernels'].items()})"
+timeout 600 python -m pytest tests/test_tp_native_gpu.py tests/test_ts_linear_gpu.py tests/test_hip_kernels.py -q > gpurun_out/r2/tests5.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r2/tests5.log
+grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/r2/tests5.log | tail -20
+SEQUOIA_TS_EXCLUSIVE=1 SEQUOIA_TP_FORCE_HOOKS=1 timeout 900 python bench.py --config E --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-autoregressive --sync-loop > gpurun_out/r2/bench_E_tp1.log 2>&1; tail -3 gpurun_out/r2/bench_E_tp1.log | cut -c1-1800
