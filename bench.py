@@ -154,46 +154,53 @@ def kernel_rooflines(cfg, loop, device):
     return res
 
 
-def cpu_baseline(cfg, n_steps=1, pair="calibrated"):
-    """The CPU path timed on this box's host cores: the same host loop with the numpy oracle ops
-    (oracle/ops_adapter.py) and PyTorch CPU GEMMs, fp16 like the reference, on a bounded sample
-    (n_steps speculation steps of the first prompt; the first includes the 255-token prefill),
-    same synthetic weight pair as the GPU run."""
+def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=False):
+    """The CPU path timed on this box's host cores: the same host loop with the reference's PyTorch op sequences
+    restated for CPU tensors (oracle/ops_torch_cpu.py; verification on the numpy oracle) and PyTorch CPU GEMMs, fp16
+    like the reference, on a bounded sample: n_steps
+    speculation steps of the first prompt.  The first step carries the 255-token target prefill (the reference's
+    timer includes it, tests/testbed.py:78-89): it is reported separately, `value` / `steps_per_s` are the steady
+    steps after it.  profiles/r02_cpu_reference_vs_port.json holds a run of the IMPORTED reference
+    (oracle/ref_cpu_baseline.py) beside this port on the same weights, prompt and noise."""
     from oracle.ops_adapter import OracleOps
+    from oracle.ops_torch_cpu import TorchCpuOps
     from sequoia_amd import ops as ops_mod
     prev = ops_mod._OPS
-    ops_mod.set_ops_for_testing(OracleOps())
+    ops_mod.set_ops_for_testing(OracleOps() if numpy_ops else TorchCpuOps())     # numpy_ops: the checking oracle (slow)
     try:
         t0 = time.perf_counter()
-        draft, target, gm = build(cfg, "cpu", pair)
+        draft, target, gm = engines if engines is not None else build(cfg, "cpu", pair)
         build_s = time.perf_counter() - t0
-        loop = Loop.__new__(Loop)
         from sequoia_amd.Tree.GreedyTree import GreedyTree
         from sequoia_amd.Tree.SpecTree import SpecTree
         M = cfg["M"]
         cls = SpecTree if cfg["mode"] == "stochastic" else GreedyTree
         p = torch.tensor(load_prompts()[0][:128], dtype=torch.long)
+        torch.manual_seed(17)
         tree = cls(prefix=p, device="cpu", temperature=0.6, top_p=1.0, draft_kv_len=0, target_kv_len=0,
                    draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
                    grow_map=gm.to_reference_dict(), attn_mask=None, sequence=None, new_tokens_buffer=None,
                    parents_buffer=None, position_ids=torch.zeros(M, dtype=torch.long), residual_graph=None,
-                   sampling_callables=None, sample_gather_indices=None)
-        t1 = time.perf_counter()
-        cur, new_tok, done = len(p), 0, 0
-        for _ in range(n_steps):
+                   sampling_callables=None, sample_gather_indices=None, commit_order="reference")
+        cur, step_s, step_tok = len(p), [], []
+        for _ in range(max(2, n_steps)):
+            t1 = time.perf_counter()
             tree.construct_grow_map()
             valid, _, _, term = tree.verify()
-            new_tok += valid.shape[0] - cur
+            step_s.append(time.perf_counter() - t1)
+            step_tok.append(valid.shape[0] - cur)
             cur = valid.shape[0]
-            done += 1
             if term:
                 break
-        dt = time.perf_counter() - t1
-        return dict(value=new_tok / dt, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
-                    sample=f"{done} speculation steps of prompt 0 (first step includes the 255-token target prefill), "
-                           f"config {cfg['draft']} -> {cfg['target']}, numpy oracle ops + torch CPU fp16 GEMMs, "
-                           f"{dt:.1f} s timed (+{build_s:.0f} s weight init)",
-                    steps_per_s=done / dt)
+        steady_s, steady_tok = sum(step_s[1:]), sum(step_tok[1:])
+        n_steady = len(step_s) - 1
+        return dict(value=(steady_tok / steady_s) if n_steady else None, unit="tokens/s", cores=torch.get_num_threads(),
+                    kind="port",
+                    sample=f"{len(step_s)} speculation steps of prompt 0, config {cfg['draft']} -> {cfg['target']}, the "
+                           f"reference's torch op sequences on CPU fp16 tensors; step 0 (with the 255-token target prefill) {step_s[0]:.1f} s, "
+                           f"then {n_steady} steady steps in {steady_s:.1f} s (+{build_s:.0f} s weight init)",
+                    steps_per_s=(n_steady / steady_s) if n_steady else None, prefill_step_s=step_s[0],
+                    step_seconds=[round(x, 3) for x in step_s], step_tokens=step_tok, tokens=valid[:cur].tolist())
     finally:
         ops_mod.set_ops_for_testing(prev)
 
@@ -274,7 +281,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave PyTorch's GEMM algorithm choice at its default")
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--growmap", default=None, help="override the config's growmap: bundled name or path (.json / reference .pt)")
     ap.add_argument("--no-autoregressive", action="store_true", help="skip the target-only baseline (simulation_baseline)")
     ap.add_argument("--no-tuned-growmap", action="store_true",
@@ -349,27 +356,31 @@ def main():
         dom = max(per_step, key=per_step.get)
         d = kr[dom]
         peak_hbm = 8000.0
-        traffic = None
-        if dom == "tree_attention_target" and args.config == "B":
-            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-            # over tools/kbench.py at this shape; gfx950 correction 2*FETCH + WRITE), profiles/r01_pmc_*.json
+        # HBM bytes per launch and MFMA utilisation of the dominant kernel: rocprofv3 PMC passes committed under profiles/
+        # (tools/pmc_r02.sh; FETCH_SIZE / WRITE_SIZE / SQ group in separate passes, gfx950 correction 2 FETCH + WRITE), keyed
+        # by the launch plan THIS run used -- a plan the passes did not cover gives traffic = null and says so
+        traffic = mfma_util = None
+        traffic_note = None
+        pmc_key = None
+        if args.config == "B":
+            if dom == "tree_attention_target":
+                pmc_key = "tree_attention_target7b"
+            elif dom.startswith("linear_ts_"):
+                pmc_key = f"{dom[len('linear_ts_'):]}@{(gm.size + 15) // 16}:{d['plan'][0]}x{d['plan'][1]}"
+        if pmc_key is not None:
             try:
-                with open(os.path.join(REPO, "profiles", "r01_pmc_tree_attention.json")) as f:
+                with open(os.path.join(REPO, "profiles", "r02_pmc.json")) as f:
                     pm = json.load(f)["kernels"]
-                traffic = pm["void tree_attention_kernel<128, true>(AttnParams)|grid=131072"]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-        elif dom.startswith("linear_ts_") and args.config == "B":
-            # same recipe over tools/ts_bench at this projection's shape and launch plan, profiles/r01_pmc_ts_linear.json
-            try:
-                with open(os.path.join(REPO, "profiles", "r01_pmc_ts_linear.json")) as f:
-                    traffic = json.load(f)["kernels"][d["pmc_key"]]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+                traffic, mfma_util = pm[pmc_key]["hbm_bytes_per_launch"], pm[pmc_key]["mfma_util"]
+            except (OSError, KeyError, ValueError) as e:
+                traffic_note = f"no PMC pass for {pmc_key} in profiles/r02_pmc.json ({type(e).__name__}): re-run tools/pmc_r02.sh"
+                print("bench.py: " + traffic_note, file=sys.stderr)
         roof = dict(bound="hbm", kernel=dom, achieved=d["bytes"] / d["seconds"] / 1e9, peak=peak_hbm, unit="GB/s",
-                    frac=d["bytes"] / d["seconds"] / 1e9 / peak_hbm, traffic=traffic,
+                    frac=d["bytes"] / d["seconds"] / 1e9 / peak_hbm, traffic=traffic, mfma_util=mfma_util, pmc_key=pmc_key,
                     avg_launch_us=d["seconds"] * 1e6, algorithmic_bytes_per_launch=d["bytes"],
                     time_per_step_us=per_step[dom] * 1e6)
+        if traffic_note:
+            roof["traffic_note"] = traffic_note
         kernels = {k: dict(avg_us=v["seconds"] * 1e6, gbps=v["bytes"] / v["seconds"] / 1e9,
                            per_step_us=per_step[k] * 1e6) for k, v in kr.items()}
         tuned = None
@@ -407,6 +418,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             try:
                 cpu = cpu_baseline(cfg, args.cpu_steps, args.pair)
+                cpu.pop("tokens", None)
             except Exception as e:  # the baseline is a report, never the measured path
                 cpu = dict(value=None, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
                            sample=f"failed: {type(e).__name__}: {e}")
@@ -420,8 +432,9 @@ def main():
                                 parallelism=(f"tp{world}" if tp_mode else ("replicas" if world > 1 else "single")), graphs=not args.no_graphs,
                                 step_loop="device-driven (one hipGraph per speculation step, results read one step late)"
                                 if loop.pipelined else "host-driven (one result read per step)",
-                                gemm="torch TunableOp (hipBLASLt/rocBLAS solution picked per shape)" if gemm_tuned
-                                else "torch default"),
+                                gemm="tree forwards (<= 144 rows): sq_linear_ts_f16 (fragment-major weight stream, plans "
+                                     "ts_plans_gfx950.json); prompt prefill and lm_head at 128 rows: PyTorch GEMM ("
+                                     + ("TunableOp-selected hipBLASLt / rocBLAS solutions" if gemm_tuned else "default algorithm") + ")"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs, rccl_ranks=rccl_ranks,
                     roofline=roof, kernels=kernels, host_driven_loop=host_loop, mi355x_growmap=tuned,
                     autoregressive_baseline=autoreg,

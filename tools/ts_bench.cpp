@@ -70,6 +70,7 @@ int main(int argc, char** argv) {
                     cands.push_back({tiles, sp});
                 }
             for (int t : {256, 512}) if (!sh.silu || true) { if ((units + t - 1) / t <= max_u && units >= t) cands.push_back({t, 1}); }
+            if (getenv("TS_TILES") && getenv("TS_SPLITS")) { cands.clear(); cands.push_back({atoi(getenv("TS_TILES")), atoi(getenv("TS_SPLITS"))}); }
             for (auto [tiles, splits] : cands) {
                 const size_t need = sq_linear_ts_workspace_bytes(m, sh.n_out, splits);
                 if (need > slab_cap) continue;
