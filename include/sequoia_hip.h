@@ -291,6 +291,19 @@ int sq_verify_specinfer_f16(const void* target_logits, const void* draft_logits,
                             int n_tree, int vocab, int gt, float temperature, uint32_t bonus_u24,
                             void* workspace, int32_t* d_result, void* stream);
 
+/* The acceptance-rate probe (tests/test_accept.py:36-140 on SpecTreeTest, Tree/SpecTree.py:283-481): a
+ * star tree whose children are sampled without replacement with FP32 noise -- torch evaluates rand.log() / q in fp32, so
+ * the keys are fp32 (sq_sample_wor_f32noise_f16; arguments as sq_sample_wor_f16, rand fp32) -- and verified with r in
+ * fp32 and the test p >= r q evaluated in fp32 (sq_verify_probe_f16; arguments as sq_verify_stochastic_f16, r fp32).   */
+int sq_sample_wor_f32noise_f16(const void* logits, int64_t ld_logits, const float* rand, int64_t ld_rand,
+                               const int32_t* d_row_ids, int n_rows, int vocab, int k, float temperature,
+                               int64_t* out, const int32_t* d_branch, const int32_t* d_out_off, void* workspace,
+                               void* stream);
+int sq_verify_probe_f16(const void* target_logits, void* draft_logits, int64_t* tokens, int token_capacity,
+                        const float* r32, const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree,
+                        int vocab, int gt, float temperature, uint32_t bonus_u24, void* workspace,
+                        int32_t* d_result, void* stream);
+
 /* GreedySTree.verify (Tree/GreedySTree.py:188-214): the walk of sq_verify_greedy_f16 against one
  * target token per node supplied by the caller (sampled from the target distribution instead of
  * the argmax); bonus = the target token of the last accepted node.  d_target_tokens: int64 [n_tree]. */

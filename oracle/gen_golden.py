@@ -60,6 +60,9 @@ def import_reference():
         def rope_theta(self):
             return 10000.0
 
+    from Tree.SpecTree import SpecTreeTest
+    from Tree.GreedyTree import GreedyTreeTest
+    globals()["_PROBES"] = dict(spectest=SpecTreeTest, greedytest=GreedyTreeTest)
     return dict(LM=LM, MM=MM, GIE=GraphInferenceEngine, GIETG=GraphInferenceEngineTG, IE=InferenceEngine,
                 IETG=InferenceEngineTG, KV=KV_Cache, SpecTree=SpecTree, GreedyTree=GreedyTree, SpecInferTree=SpecInferTree,
                 GreedySTree=GreedySTree, RU=RU,
@@ -316,6 +319,83 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
           f"({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def run_probe_case(R, name, mode, dims, vocab, M, T, width, prompt_len, max_steps, seed, logit_gain=8.0, noise=0.05,
+                   out_dir=None):
+    """The acceptance-rate probes: the loop of tests/test_accept.py:36-140 on the reference's own
+    SpecTreeTest / GreedyTreeTest (Tree/SpecTree.py:283-481, Tree/GreedyTree.py:267-456) -- a fresh star tree of `width`
+    children per step, KV lengths carried over.  Weights are seeded (oracle/seeded_weights.py); recorded per step: the
+    prefix, the fp32 noise the constructor drew, the sampled children, draft / target logits and the 5-tuple."""
+    from oracle import seeded_weights as SW
+    cls = _PROBES[mode]
+    cfg = make_cfg(R, dims, vocab)
+    draft = make_engine(R, R["GIE"], R["IE"], R["MM"].LlamaForCausalLM_FI, cfg, M, 1, 1.0)
+    target = make_engine(R, R["GIETG"], R["IETG"], R["MM"].LlamaForCausalLM_TG, cfg, M, 2, 1.0)
+    sd_t = SW.seeded_state_dict(dims, vocab, 1000 + seed, logit_gain)
+    sd_d = SW.correlate(SW.seeded_state_dict(dims, vocab, 2000 + seed, logit_gain), sd_t, noise, 3000 + seed)
+    for eng, sd in ((draft, sd_d), (target, sd_t)):
+        missing, unexpected = eng.engine.model.load_state_dict(sd, strict=False)
+        assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing)
+    arrays = {}
+    torch.manual_seed(seed)
+    input_ids = torch.randint(3, vocab, (prompt_len,))
+    arrays["prompt"] = input_ids.numpy()
+    u24 = np.random.RandomState(seed + 1).randint(0, 1 << 24, size=max_steps + 4).astype(np.int64)
+    arrays["bonus_u24"] = u24
+    box = {"i": 0}
+    orig_multinomial = torch.Tensor.multinomial
+
+    def fake_multinomial(self, num_samples=1, replacement=False, generator=None):
+        return torch.tensor([ops_np.inverse_cdf(self.detach().clone().numpy(), int(u24[box["i"]]))], dtype=torch.long)
+    torch.Tensor.multinomial = fake_multinomial
+    attn_mask = torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16)
+    position_ids = torch.zeros(M).long()
+    try:
+        torch.manual_seed(seed + 7)                 # every constructor draws r, then rand, from this stream
+        dkv = tkv = 0
+        step, terminal = 0, False
+        while step < max_steps and not terminal and input_ids.shape[0] + width + 1 < M:
+            box["i"] = step
+            attn_mask.fill_(torch.finfo(torch.float16).min)
+            raw = {}
+            orig_inf = target.inference
+
+            def spy(**kw):
+                out = orig_inf(**kw)
+                raw["logits"] = out
+                return out
+            target.inference = spy
+            tree = cls(prefix=input_ids, device="cpu", temperature=T, top_p=1.0, draft_kv_len=dkv, target_kv_len=tkv,
+                       draft_model_engine=draft, target_model_engine=target, max_length=M, attn_mask=attn_mask, sequence=None,
+                       new_tokens_buffer=None, parents_buffer=None, position_ids=position_ids, max_width=width)
+            pre = f"step{step}"
+            arrays[f"{pre}/prefix"] = input_ids.numpy().copy()
+            arrays[f"{pre}/kv_lens"] = np.array([dkv, tkv], dtype=np.int64)
+            arrays[f"{pre}/tokens_pre"] = tree.tokens.numpy().copy()
+            arrays[f"{pre}/draft_logits"] = tree.draft_logits.numpy().copy()
+            if mode == "spectest":
+                arrays[f"{pre}/r32"] = tree.r.numpy().copy()
+                arrays[f"{pre}/rand32"] = tree.rand.numpy().copy()
+            valid, a, _, b, terminal = tree.verify(benchmark=True)
+            target.inference = orig_inf
+            arrays[f"{pre}/target_logits"] = raw["logits"][0][-(width + 1):].numpy().copy()
+            arrays[f"{pre}/valid_tokens"] = valid.numpy().copy()
+            arrays[f"{pre}/a_b_terminal"] = np.array([a, b, int(terminal)], dtype=np.int64)
+            input_ids = valid.clone()
+            dkv = tkv = a
+            step += 1
+        arrays["n_steps"] = np.int64(step)
+    finally:
+        torch.Tensor.multinomial = orig_multinomial
+    meta = dict(name=name, mode=mode, dims=list(dims), vocab=vocab, M=M, T=T, width=width, prompt_len=prompt_len, seed=seed,
+                logit_gain=logit_gain, noise=noise, torch=torch.__version__,
+                seeded=dict(draft_seed=2000 + seed, target_seed=1000 + seed, share_seed=3000 + seed,
+                            draft_checksum=str(SW.checksum(sd_d)), target_checksum=str(SW.checksum(sd_t))))
+    arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(out_dir, f"trace_{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: steps={step} terminal={terminal} final_len={input_ids.shape[0]} -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def gen_rows_fullvocab(R, out_dir):
     """Single-row sampler / residual cases at the real vocabulary size (V = 32000) produced by
     the reference's own functions (utils.py:5-18,29-32)."""
@@ -345,9 +425,10 @@ def main():
     R = import_reference()
     out_dir = os.path.join(REPO, "tests", "golden")
     only = set(sys.argv[1:])                       # e.g. `python oracle/gen_golden.py D_160m13b V32k_seq128`
-    global run_case, gen_rows_fullvocab
+    global run_case, gen_rows_fullvocab, run_probe_case
     if only:
-        _run, _rows = run_case, gen_rows_fullvocab
+        _run, _rows, _probe = run_case, gen_rows_fullvocab, run_probe_case
+        run_probe_case = lambda R_, name, *a, **k: _probe(R_, name, *a, **k) if name in only else None
         run_case = lambda R_, name, *a, **k: _run(R_, name, *a, **k) if name in only else None
         gen_rows_fullvocab = lambda R_, d: _rows(R_, d) if "rows" in only else None
     # head dims are the ones the native attention kernel is built for (64 and 128)
@@ -386,6 +467,9 @@ def main():
     run_case(R, "V32k_seq128", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), d68, t160, 32000,
              384, 0.6, "stochastic", 32, 5, 25, logit_gain=10.0, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.005,
              out_dir=out_dir)
+    # the acceptance-rate probes of tests/test_accept.py (fp32 noise, p >= r q in fp32; top-k children / argmax)
+    run_probe_case(R, "P_spectest", "spectest", tiny, 1024, 128, 0.6, 8, 16, 12, 31, noise=0.6, out_dir=out_dir)
+    run_probe_case(R, "Q_greedytest", "greedytest", tiny, 1024, 128, 0.6, 8, 16, 12, 32, noise=0.6, out_dir=out_dir)
     gen_rows_fullvocab(R, out_dir)
 
 

@@ -132,6 +132,18 @@ class OracleOps:
         self._emit(O.sample_wor(_np(logits)[rows], _np(rand)[rows], k, temperature), out, branch, out_off, out_base)
         return out
 
+    def sample_wor_f32noise(self, logits, rand32, row_ids, k, temperature, out, branch=None, out_off=None):
+        rows = _np(row_ids).astype(np.int64) if row_ids is not None else np.arange(logits.shape[0])
+        self._emit(O.sample_wor_f32noise(_np(logits)[rows], _np(rand32)[rows], k, temperature)[0], out, branch, out_off)
+        return out
+
+    def verify_probe(self, target_logits, draft_logits, tokens, r32, child_off, child_ids, n_tree, gt, temperature, u24,
+                     workspace, result):
+        succ = _succ_from_csr(child_off, child_ids, n_tree)
+        self._fill(result, O.verify_probe(_np(target_logits), _np(draft_logits), _np(tokens), _np(r32), succ, gt, temperature,
+                                          int(u24) & 0xffffff))
+        return result
+
     def topk(self, logits, row_ids, k, out, branch=None, out_off=None, out_base=None):
         rows = _np(row_ids).astype(np.int64) if row_ids is not None else np.arange(logits.shape[0])
         self._emit(O.topk_ids(_np(logits)[rows], k), out, branch, out_off, out_base)

@@ -273,7 +273,7 @@ def inverse_cdf(p16, u24):
     return int(np.searchsorted(c, thr, side="right"))
 
 
-def accept_children(p16, draft_row16, child_tokens, child_r16, temperature, margins=None, replace=False):
+def accept_children(p16, draft_row16, child_tokens, child_r16, temperature, margins=None, replace=False, probe=False):
     """accept_step (Tree/SpecTree.py:136-157) for one parent; replace=True is SpecInfer's rule
     (Tree/SpecInferTree.py:141-164): p >= r q, and a rejection leaves q and the draft logits untouched.
 
@@ -284,10 +284,18 @@ def accept_children(p16, draft_row16, child_tokens, child_r16, temperature, marg
     n_rej = 0
     for j, (tok, r) in enumerate(zip(child_tokens, child_r16)):
         q16 = scaled_softmax_f16(draft_row16, temperature)
-        rq = h(f(np.float16(r)) * f(q16[tok]))
-        if margins is not None:
-            margins.append(float(f(p16[tok]) - f(rq)))
-        if (p16[tok] >= rq) if replace else (p16[tok] > rq):
+        if probe:
+            # SpecTreeTest.accept_step (Tree/SpecTree.py:412): r is fp32, r * q[token] and the comparison are fp32
+            rq32 = np.float32(r) * np.float32(q16[tok])
+            if margins is not None:
+                margins.append(float(np.float32(p16[tok]) - rq32))
+            ok = np.float32(p16[tok]) >= rq32
+        else:
+            rq = h(f(np.float16(r)) * f(q16[tok]))
+            if margins is not None:
+                margins.append(float(f(p16[tok]) - f(rq)))
+            ok = (p16[tok] >= rq) if replace else (p16[tok] > rq)
+        if ok:
             return j, p16, n_rej
         p16, _ = residual_f16(p16, q16)
         if not replace:
@@ -297,7 +305,7 @@ def accept_children(p16, draft_row16, child_tokens, child_r16, temperature, marg
 
 
 def verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, gt, temperature,
-                      u24, margins=None, replace=False, gather_first=False):
+                      u24, margins=None, replace=False, gather_first=False, probe=False):
     """SpecTree.verify from the softmax to the token compaction (Tree/SpecTree.py:196-224).
 
     target_logits16: [n, V]; draft_logits16: [>=n, V] tree-local rows (mutated); tokens: int64[M]
@@ -314,7 +322,7 @@ def verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, 
             break
         ctoks = [int(tokens[c + gt - 1]) for c in ch]
         crs = [r16[c + gt - 1] for c in ch]
-        j, p, _ = accept_children(p_all[node], draft_logits16[node], ctoks, crs, temperature, margins, replace)
+        j, p, _ = accept_children(p_all[node], draft_logits16[node], ctoks, crs, temperature, margins, replace, probe)
         if j < 0:
             break
         node = ch[j]
@@ -513,3 +521,25 @@ def verify_tokens(target_tokens, tokens, successors, gt):
         tokens[a] = bonus
     return dict(accept_len=a, n_tree=len(slots), bonus=bonus, terminal=int(terminal), reason=reason, gt=gt,
                 last_node=node, slots=slots)
+
+
+# ---- the acceptance-rate probe: SpecTreeTest, Tree/SpecTree.py:283-481 -------------------------------
+def sample_wor_f32noise(logits16, rand32, k, temperature):
+    """SpecTreeTest.collective_grow_static (Tree/SpecTree.py:349-360): the noise is fp32, so torch evaluates
+    rand.log() / softmax(logits / T) in fp32 (fp32 / fp16 promotes); the k largest keys per row, descending."""
+    q = scaled_softmax_f16(logits16, temperature)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        keys = np.log(rand32.astype(np.float32)).astype(np.float32) / q.astype(np.float32)
+    out = np.zeros((keys.shape[0], k), dtype=np.int64)
+    for r in range(keys.shape[0]):
+        kr = keys[r].copy()
+        kr[np.isnan(kr)] = np.inf
+        out[r] = np.lexsort((np.arange(kr.shape[0]), -kr))[:k]
+    return out, keys
+
+
+def verify_probe(target_logits16, draft_logits16, tokens, r32, successors, gt, temperature, u24, margins=None):
+    """SpecTreeTest.verify (Tree/SpecTree.py:419-481): Sequoia's walk with fp32 r and the fp32 test p >= r q; the accepted
+    tokens are gathered before the bonus token is appended (:472-474)."""
+    return verify_stochastic(target_logits16, draft_logits16, tokens, r32, successors, gt, temperature, u24, margins,
+                             gather_first=True, probe=True)

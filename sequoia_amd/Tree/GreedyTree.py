@@ -28,7 +28,10 @@ class GreedyTree(NativeTree):
 
 class GreedyTreeTest(GreedyTree):
     """GreedyTree on a star growmap of `max_width` children (reference: Tree/GreedyTree.py:267-456, used by
-    tests/test_accept.py to measure which of the top-k draft tokens the target picks); verify() also returns b."""
+    tests/test_accept.py to measure which of the top-k draft tokens the target picks); verify() also returns b.  Like the
+    reference's probe it is rebuilt every step: the KV caches are rolled back to the accepted path and no next-root
+    forward runs (the next probe's constructor feeds the bonus token)."""
+    _prepare_next = False
 
     def __init__(self, draft_model_engine, target_model_engine, prefix, temperature: float = 0.6, top_p: float = 0.9,
                  draft_kv_len=0, target_kv_len=0, max_length=256, max_width=32, device="cpu", attn_mask=None,
@@ -41,7 +44,7 @@ class GreedyTreeTest(GreedyTree):
                          temperature=temperature, top_p=top_p, draft_kv_len=draft_kv_len, target_kv_len=target_kv_len,
                          max_length=max_length, device=device, max_target_seq=max_length, vocab_size=vocab, grow_map=gm,
                          attn_mask=attn_mask, sequence=sequence, new_tokens_buffer=new_tokens_buffer,
-                         parents_buffer=parents_buffer, position_ids=position_ids)
+                         parents_buffer=parents_buffer, position_ids=position_ids, step_graph=False)
         self.construct_grow_map()
 
     def verify(self, benchmark=False):

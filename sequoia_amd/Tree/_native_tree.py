@@ -90,7 +90,7 @@ class NativeTree(Tree):
         self.ground_truth_len = gt
         if self.stochastic:
             # same CPU-generator draws, in the same order, as the reference (Tree/SpecTree.py:60,84)
-            self.r = torch.rand(len(position_ids), dtype=self.dtype).to(self.device)
+            self.r = self._draw_r(len(position_ids)).to(self.device)
             if self.state is not None:
                 self.state.r[:len(self.r)].copy_(self.r)
                 self.r = self.state.r
@@ -145,6 +145,10 @@ class NativeTree(Tree):
             self.rand = self.state.rand
         else:
             self.rand = rand.to(self.device)
+
+    def _draw_r(self, m: int):
+        """The acceptance uniforms r[slot] (Tree/SpecTree.py:60: fp16, drawn on the CPU generator)."""
+        return torch.rand(m, dtype=self.dtype)
 
     def _ctx(self, q_slot0: int, kv_len: int) -> TreeContext:
         # storage_ids = arange(M) (Tree/SpecTree.py:63): the queries' KV slots are q_slot0 + arange(q_len)
@@ -241,7 +245,8 @@ class NativeTree(Tree):
         if not terminal:
             if benchmark:
                 _sync(self.device); t4 = time.time()
-            self.prepare_for_next_iter(accept_list, self.tokens[:accept_length + 1])
+            if self._prepare_next:
+                self.prepare_for_next_iter(accept_list, self.tokens[:accept_length + 1])
             if benchmark:
                 return self.tokens[:accept_length + 1], accept_length, accept_length, t2 - t1, t3 - t2, t4 - t3, terminal
             return self.tokens[:accept_length + 1], accept_length, accept_length, terminal
@@ -278,6 +283,7 @@ class NativeTree(Tree):
         self.target_kv_len = a
 
     _compact_when_terminal = True
+    _prepare_next = True       # the acceptance probes rebuild the tree every step: no next-root forward (Tree/SpecTree.py:283)
 
     # ---- device-driven steps (Tree/step_graph.py) ------------------------------------------------------------------
     def begin_pipeline(self):

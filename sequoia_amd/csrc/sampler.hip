@@ -131,9 +131,19 @@ __device__ __forceinline__ void wave_topk(C (&comp)[NPL], int used, int n_out, i
     }
 }
 
-template <bool WOR, typename C>
+// fp32 -> sortable unsigned 32-bit (larger float => larger unsigned; NaN largest)
+__device__ __forceinline__ uint32_t f32_to_ordered(float x) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, x);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return 0xfffffffeu;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// WOR: 0 = top-k of the raw logits, 1 = sampling without replacement with fp16 noise (SpecTree), 2 = the acceptance
+// probe's form (SpecTreeTest, Tree/SpecTree.py:349-360): fp32 noise, key = log(u) / q evaluated in fp32 (torch promotes
+// fp32 / fp16), 64-bit composites with the 32-bit ordered key
+template <int WOR, typename C>
 __global__ void __launch_bounds__(PART_THREADS)
-sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const half_t* __restrict__ rnd, int64_t ld_rand,
+sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const void* __restrict__ rnd_raw, int64_t ld_rand,
                     const int32_t* __restrict__ row_ids, int vocab, int k, float temperature,
                     const float* __restrict__ stats, int stats_by_source_row, const int32_t* __restrict__ branch,
                     C* __restrict__ cand) {
@@ -148,8 +158,40 @@ sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const 
     const half_t* x = logits + row * ld_logits;
 
     C comp[EPT];
-    if (WOR) {
-        const half_t* u = rnd + row * ld_rand;
+    if (WOR == 2) {
+        const float* u = (const float*)rnd_raw + row * ld_rand;
+        half8 xv[PART_CH];
+        float uv[PART_CH][8];
+#pragma unroll
+        for (int c = 0; c < PART_CH; ++c) {
+            const int e0 = part_elem(p, c, t, 0);
+            if (e0 < vocab) {
+                xv[c] = *(const half8*)(x + e0);
+                const floatx4 a = *(const floatx4*)(u + e0), b = *(const floatx4*)(u + e0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { uv[c][j] = a[j]; uv[c][4 + j] = b[j]; }
+            }
+        }
+        float M, z;
+        combine_stats(stats + (size_t)(stats_by_source_row ? row : r) * parts * 2, parts, M, z);
+#pragma unroll
+        for (int c = 0; c < PART_CH; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = part_elem(p, c, t, j);
+                C v = 0;
+                if (part_elem(p, c, t, 0) < vocab) {
+                    const float yy = (float)(half_t)div_rn((float)xv[c][j], temperature);
+                    const half_t q = (half_t)div_rn(exp_fast(yy - M), z);
+                    const float lu = log_fast(uv[c][j]);
+                    const float key = (q == (half_t)0.0f) ? -INFINITY : div_rn(lu, (float)q);
+                    v = ((C)f32_to_ordered(key) << (sizeof(C) * 4)) + (C)1 + (C)(0xfffffffeu - (uint32_t)e);
+                }
+                comp[c * 8 + j] = v;
+            }
+        }
+    } else if (WOR == 1) {
+        const half_t* u = (const half_t*)rnd_raw + row * ld_rand;
         half8 xv[PART_CH], uv[PART_CH];
 #pragma unroll
         for (int c = 0; c < PART_CH; ++c) {
@@ -239,7 +281,7 @@ static int check_rows(const void* logits, int64_t ld, int n_rows, int vocab, int
     return SQ_OK;
 }
 
-template <bool WOR, typename C>
+template <int WOR, typename C>
 static int launch_sampler(const void* logits, int64_t ld_logits, const void* rnd, int64_t ld_rand, const int32_t* row_ids,
                           int n_rows, int vocab, int k, float temperature, int64_t* out, const int32_t* branch,
                           const int32_t* out_off, const int32_t* out_base, const float* stats, int by_source_row,
@@ -247,7 +289,7 @@ static int launch_sampler(const void* logits, int64_t ld_logits, const void* rnd
     const int parts = samp_parts(vocab);
     C* cand = (C*)((char*)workspace + samp_stats_bytes(n_rows, vocab));
     hipLaunchKernelGGL((sample_parts_kernel<WOR, C>), dim3(n_rows, parts), dim3(PART_THREADS), 0, st, (const half_t*)logits,
-                       ld_logits, (const half_t*)rnd, ld_rand, row_ids, vocab, k, temperature, stats, by_source_row, branch,
+                       ld_logits, rnd, ld_rand, row_ids, vocab, k, temperature, stats, by_source_row, branch,
                        cand);
     int rc = sq_check_launch();
     if (rc != SQ_OK) return rc;
@@ -293,9 +335,9 @@ extern "C" int sq_sample_wor_f16(const void* logits, int64_t ld_logits, const vo
         by_source = 0;
     }
     if (vocab <= 65536)
-        return launch_sampler<true, uint32_t>(logits, ld_logits, rnd, ld_rand, d_row_ids, n_rows, vocab, k, temperature, out,
+        return launch_sampler<1, uint32_t>(logits, ld_logits, rnd, ld_rand, d_row_ids, n_rows, vocab, k, temperature, out,
                                               d_branch, d_out_off, d_out_base, stats, by_source, workspace, st);
-    return launch_sampler<true, unsigned long long>(logits, ld_logits, rnd, ld_rand, d_row_ids, n_rows, vocab, k, temperature,
+    return launch_sampler<1, unsigned long long>(logits, ld_logits, rnd, ld_rand, d_row_ids, n_rows, vocab, k, temperature,
                                                     out, d_branch, d_out_off, d_out_base, stats, by_source, workspace, st);
 }
 
@@ -307,8 +349,25 @@ extern "C" int sq_topk_f16(const void* logits, int64_t ld_logits, const int32_t*
     if (n_rows == 0) return SQ_OK;
     hipStream_t st = (hipStream_t)stream;
     if (vocab <= 65536)
-        return launch_sampler<false, uint32_t>(logits, ld_logits, nullptr, 0, d_row_ids, n_rows, vocab, k, 1.0f, out, d_branch,
+        return launch_sampler<0, uint32_t>(logits, ld_logits, nullptr, 0, d_row_ids, n_rows, vocab, k, 1.0f, out, d_branch,
                                                d_out_off, d_out_base, nullptr, 0, workspace, st);
-    return launch_sampler<false, unsigned long long>(logits, ld_logits, nullptr, 0, d_row_ids, n_rows, vocab, k, 1.0f, out,
+    return launch_sampler<0, unsigned long long>(logits, ld_logits, nullptr, 0, d_row_ids, n_rows, vocab, k, 1.0f, out,
                                                      d_branch, d_out_off, d_out_base, nullptr, 0, workspace, st);
+}
+
+// The acceptance-rate probe's sampler (SpecTreeTest.collective_grow_static, Tree/SpecTree.py:349-360): the noise is
+// fp32 and torch evaluates rand.log() / q in fp32 (q is the fp16 softmax), so the keys are fp32.
+extern "C" int sq_sample_wor_f32noise_f16(const void* logits, int64_t ld_logits, const float* rnd, int64_t ld_rand,
+                                          const int32_t* d_row_ids, int n_rows, int vocab, int k, float temperature,
+                                          int64_t* out, const int32_t* d_branch, const int32_t* d_out_off, void* workspace,
+                                          void* stream) {
+    int rc = check_rows(logits, ld_logits, n_rows, vocab, k, out, d_branch, d_out_off, workspace);
+    if (rc != SQ_OK) return rc;
+    if (!rnd || ld_rand < vocab || (ld_rand & 3) || ((uintptr_t)rnd & 15) || !(temperature > 0.f)) return SQ_EINVAL;
+    if (n_rows == 0) return SQ_OK;
+    rc = sq_logits_stats_f16(logits, ld_logits, d_row_ids, n_rows, vocab, temperature, (float*)workspace, 0, nullptr, 0, stream);
+    if (rc != SQ_OK) return rc;
+    return launch_sampler<2, unsigned long long>(logits, ld_logits, rnd, ld_rand, d_row_ids, n_rows, vocab, k, temperature, out,
+                                                 d_branch, d_out_off, nullptr, (const float*)workspace, 0, workspace,
+                                                 (hipStream_t)stream);
 }

@@ -222,14 +222,17 @@ __device__ __forceinline__ int step_gt(const int32_t* d_step, int gt) { return d
 // its exponentials e = exp(y - mx) (fp32, computed once per maximum).  One rejection = one pass over the registers
 // (p <- h(d / sf); q <- h(e / z); d <- relu(h(p - q)); exact integer sum of d; fresh sum / maximum of the draft without the
 // rejected token) and one block reduction.
-template <int EPT, bool REPLACE>
+// RULE 2 = the acceptance-rate probe (SpecTreeTest.accept_step, Tree/SpecTree.py:396-417): r is fp32, torch promotes
+// r * q[token] and the comparison to fp32, and the test is p >= r q; rejections mask q like RULE 0.
+template <int EPT, int RULE>
 __global__ void __launch_bounds__(VER_THREADS)
 verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __restrict__ draft_logits,
-                    const int64_t* __restrict__ tokens, const half_t* __restrict__ r16,
+                    const int64_t* __restrict__ tokens, const void* __restrict__ r_raw,
                     const int32_t* __restrict__ child_off, const int32_t* __restrict__ child_ids, int n_tree,
                     int vocab, int gt_arg, float temperature, uint32_t u24_arg, void* ws_raw,
                     const int32_t* __restrict__ d_step, const uint32_t* __restrict__ d_bonus, int n_bonus) {
     constexpr int CH = EPT / 8;
+    constexpr bool REPLACE = RULE == 1;
     __shared__ float s_f[VER_WAVES];
     __shared__ float s_m[VER_WAVES];
     __shared__ float s_s[VER_WAVES];
@@ -283,7 +286,7 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             const int child = child_ids[c0 + jc];
             const int slot = child + gt - 1;
             const int tok = (int)tokens[slot];
-            const half_t rr = r16[slot];
+            const float rr = (RULE == 2) ? ((const float*)r_raw)[slot] : (float)((const half_t*)r_raw)[slot];
             // element tok lives in thread (tok/8) % THREADS at register (tok/8/THREADS)*8 + tok%8:
             // a scalar index compare instead of 32 per-thread element ids held in registers
             const bool mine = t == ((tok >> 3) & (VER_THREADS - 1));
@@ -300,8 +303,14 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             const float e_tok = s_tok[0];
             const half_t q_tok = (half_t)div_z(e_tok);
             const half_t p_tok = (half_t)s_tok[1];
-            const half_t rq = (half_t)((float)rr * (float)q_tok);
-            const bool ok = (tok >= 0 && tok < vocab) && (REPLACE ? (p_tok >= rq) : (p_tok > rq));   // Tree/SpecTree.py:152 (strict)
+            bool ok;
+            if (RULE == 2) {
+                ok = (float)p_tok >= rr * (float)q_tok;                      // fp32 product and comparison (:412)
+            } else {
+                const half_t rq = (half_t)(rr * (float)q_tok);
+                ok = REPLACE ? (p_tok >= rq) : (p_tok > rq);                  // Tree/SpecTree.py:152 (strict)
+            }
+            ok = ok && (tok >= 0 && tok < vocab);
             if (ok) { accepted = child; break; }
             // reject: p <- relu(p - q) / sum(relu(p - q));  draft_logits[tok] <- -65504 (=> q[tok] = 0)
             uint32_t lint = 0u;
@@ -460,7 +469,8 @@ struct StepArgs {                       // optional device-driven extras of the 
 static int verify_stochastic_impl(const void* target_logits, void* draft_logits, int64_t* tokens, const void* r,
                                   const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree, int vocab, int gt,
                                   float temperature, uint32_t bonus_u24, void* workspace, int32_t* d_result, void* stream,
-                                  bool replace, const StepArgs& sa) {
+                                  int rule, const StepArgs& sa) {
+    const bool replace = rule == 1;
     if (!target_logits || !draft_logits || !tokens || !r || !d_child_off || !workspace || !d_result) return SQ_EINVAL;
     if (n_tree <= 0 || n_tree > SQ_MAX_TREE || vocab <= 0 || (!sa.d_step && gt < 1) || !(temperature > 0.f)) return SQ_EINVAL;
     if (n_tree > 1 && !d_child_ids) return SQ_EINVAL;
@@ -473,11 +483,11 @@ static int verify_stochastic_impl(const void* target_logits, void* draft_logits,
     dim3 g(n_tree), b(VER_THREADS);
 #define SQ_LAUNCH(EPT, REP)                                                                                     \
     hipLaunchKernelGGL((verify_nodes_kernel<EPT, REP>), g, b, 0, st, (const half_t*)target_logits,               \
-                       (const half_t*)draft_logits, (const int64_t*)tokens, (const half_t*)r, d_child_off,        \
+                       (const half_t*)draft_logits, (const int64_t*)tokens, (const void*)r, d_child_off,          \
                        d_child_ids, n_tree, vocab, gt, temperature, bonus_u24, workspace, (const int32_t*)sa.d_step, \
                        sa.d_bonus, sa.n_bonus)
-    if (vocab <= 8 * VER_THREADS) { if (replace) SQ_LAUNCH(8, true); else SQ_LAUNCH(8, false); }
-    else if (vocab <= 32 * VER_THREADS) { if (replace) SQ_LAUNCH(32, true); else SQ_LAUNCH(32, false); }
+    if (vocab <= 8 * VER_THREADS) { if (rule == 1) SQ_LAUNCH(8, 1); else if (rule == 2) SQ_LAUNCH(8, 2); else SQ_LAUNCH(8, 0); }
+    else if (vocab <= 32 * VER_THREADS) { if (rule == 1) SQ_LAUNCH(32, 1); else if (rule == 2) SQ_LAUNCH(32, 2); else SQ_LAUNCH(32, 0); }
     else return SQ_EUNSUPPORTED;
 #undef SQ_LAUNCH
     int rc = sq_check_launch();
@@ -495,7 +505,7 @@ extern "C" int sq_verify_stochastic_f16(const void* target_logits, void* draft_l
                                         int32_t* d_result_ring, void* stream) {
     const StepArgs sa{token_capacity, d_step, d_bonus_u24, n_bonus, d_result_ring};
     return verify_stochastic_impl(target_logits, draft_logits, tokens, r, d_child_off, d_child_ids, n_tree, vocab, gt,
-                                  temperature, bonus_u24, workspace, d_result, stream, false, sa);
+                                  temperature, bonus_u24, workspace, d_result, stream, 0, sa);
 }
 
 extern "C" int sq_verify_specinfer_f16(const void* target_logits, const void* draft_logits, int64_t* tokens,
@@ -504,7 +514,19 @@ extern "C" int sq_verify_specinfer_f16(const void* target_logits, const void* dr
                                        uint32_t bonus_u24, void* workspace, int32_t* d_result, void* stream) {
     const StepArgs sa{token_capacity, nullptr, nullptr, 0, nullptr};
     return verify_stochastic_impl(target_logits, (void*)draft_logits, tokens, r, d_child_off, d_child_ids, n_tree, vocab,
-                                  gt, temperature, bonus_u24, workspace, d_result, stream, true, sa);
+                                  gt, temperature, bonus_u24, workspace, d_result, stream, 1, sa);
+}
+
+// SpecTreeTest.verify (Tree/SpecTree.py:396-481), the acceptance-rate probe of tests/test_accept.py: Sequoia's walk with r in
+// fp32 and the test p >= r q evaluated in fp32.  The walker gathers first (the probe concatenates the accepted tokens and the
+// bonus token, :472-474): pass SQ_VERIFY_GATHER_FIRST.
+extern "C" int sq_verify_probe_f16(const void* target_logits, void* draft_logits, int64_t* tokens, int token_capacity,
+                                   const float* r32, const int32_t* d_child_off, const int32_t* d_child_ids, int n_tree,
+                                   int vocab, int gt, float temperature, uint32_t bonus_u24, void* workspace,
+                                   int32_t* d_result, void* stream) {
+    const StepArgs sa{token_capacity, nullptr, nullptr, 0, nullptr};
+    return verify_stochastic_impl(target_logits, draft_logits, tokens, r32, d_child_off, d_child_ids, n_tree, vocab, gt,
+                                  temperature, bonus_u24, workspace, d_result, stream, 2, sa);
 }
 
 // ---- i.i.d. draws from softmax(logits / T) (SpecInfer's draft expansion, Tree/SpecInferTree.py:104-109) ------------

@@ -50,6 +50,8 @@ PROTOTYPES = {
     "sq_verify_workspace_bytes": (C.c_size_t, [_i]),
     "sq_sample_iid_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "sq_verify_specinfer_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp]),
+    "sq_sample_wor_f32noise_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "sq_verify_probe_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp]),
     "sq_verify_tokens_f16": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "sq_verify_stochastic_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp, _vp, _vp, _vp, _i, _vp,
                                       _vp]),

@@ -243,6 +243,32 @@ class HipOps:
                                          self._stream()), "sq_sample_wor_f16")
         return out
 
+    def sample_wor_f32noise(self, logits, rand32, row_ids, k, temperature, out, branch=None, out_off=None):
+        """The acceptance probe's sampler: fp32 noise, fp32 keys (SpecTreeTest, Tree/SpecTree.py:349-360)."""
+        _need(logits, torch.float16, "logits", contiguous=False); _need(rand32, torch.float32, "rand32", contiguous=False)
+        assert logits.stride(1) == 1 and rand32.stride(1) == 1
+        _need(out, torch.int64, "out", contiguous=False)
+        n_rows = row_ids.shape[0] if row_ids is not None else logits.shape[0]
+        ws = self._sample_ws(logits.device, n_rows, logits.shape[1], k)
+        check(self.lib.sq_sample_wor_f32noise_f16(logits.data_ptr(), logits.stride(0), rand32.data_ptr(), rand32.stride(0),
+                                                  _ptr(row_ids), n_rows, logits.shape[1], k, float(temperature),
+                                                  out.data_ptr(), _ptr(branch), _ptr(out_off), ws.data_ptr(), self._stream()),
+              "sq_sample_wor_f32noise_f16")
+        return out
+
+    def verify_probe(self, target_logits, draft_logits, tokens, r32, child_off, child_ids, n_tree, gt, temperature, u24,
+                     workspace, result):
+        """The acceptance probe's verifier: r fp32, p >= r q in fp32 (SpecTreeTest.accept_step, Tree/SpecTree.py:396-417)."""
+        _need(target_logits, torch.float16, "target_logits"); _need(draft_logits, torch.float16, "draft_logits")
+        _need(tokens, torch.int64, "tokens"); _need(r32, torch.float32, "r32")
+        _need(child_off, torch.int32, "child_off"); _need(result, torch.int32, "result")
+        vocab = target_logits.shape[-1]
+        check(self.lib.sq_verify_probe_f16(target_logits.data_ptr(), draft_logits.data_ptr(), tokens.data_ptr(), tokens.numel(),
+                                           r32.data_ptr(), child_off.data_ptr(), _ptr(child_ids), n_tree, vocab, int(gt),
+                                           float(temperature), int(u24), workspace.data_ptr(), result.data_ptr(),
+                                           self._stream()), "sq_verify_probe_f16")
+        return result
+
     def topk(self, logits, row_ids, k, out, branch=None, out_off=None, out_base=None):
         _need(logits, torch.float16, "logits", contiguous=False)
         assert logits.stride(1) == 1
