@@ -149,20 +149,6 @@ int sq_tree_attention_f16(const void* q, const void* k_layer, const void* v_laye
                           const uint64_t* d_bitmask, int words, const int32_t* d_ctx,
                           void* stream);
 
-/* Fused form of sq_rope_kv_write_f16 + sq_tree_attention_f16 (implicit tree mask) for the case where
- * the q_len new tokens occupy the contiguous slots [q_slot0, q_slot0 + q_len) == [kv_len - q_len, kv_len)
- * (always true for SpecTree / GreedyTree: storage_ids = arange(M), Tree/SpecTree.py:63).  Queries and the
- * new keys are rotated on the fly from the packed projection output `qkv` (same fp16 rounding as
- * sq_rope_kv_write_f16); one workgroup per KV head also writes the rotated K rows and the V rows into
- * their cache slots, so one launch replaces two.  Arguments as in the two functions above.          */
-int sq_rope_tree_attention_f16(const void* qkv, int qkv_stride, void* k_layer, void* v_layer,
-                               const void* cos_tab, const void* sin_tab,
-                               const int64_t* d_position_ids, void* out,
-                               int q_len, int n_heads, int h_kv, int d, int m, int kv_len, float scale,
-                               int q_slot0, int gt, int n_tree,
-                               const uint64_t* d_bitmask, int words, const int32_t* d_ctx,
-                               void* stream);
-
 /* Stream-ordered store of up to four int32 values into device memory (dst[0..n)); used to
  * update a d_ctx block between graph replays without a host->device copy.                    */
 int sq_store_i32(int32_t* dst, int n, int v0, int v1, int v2, int v3, void* stream);

@@ -104,17 +104,6 @@ class OracleOps:
         out.copy_(torch.from_numpy(O.tree_attention(_np(q), _np(k_layer), _np(v_layer), kv_len, scale, mask)))
         return out
 
-    def rope_tree_attention(self, qkv, k_layer, v_layer, cos, sin, position_ids, out, n_heads, h_kv, d, kv_len, scale,
-                            q_slot0, gt, n_tree, bitmask, ctx=None):
-        if ctx is not None:
-            q_slot0, gt, kv_len = (int(x) for x in ctx[:3])
-        q_len = qkv.shape[0]
-        sid = torch.arange(q_slot0, q_slot0 + q_len)
-        q_rot = torch.empty((n_heads, q_len, d), dtype=qkv.dtype)
-        self.rope_kv_write(qkv, q_rot, k_layer, v_layer, cos, sin, position_ids, sid, n_heads, h_kv, d)
-        return self.tree_attention(q_rot, k_layer, v_layer, out, kv_len, scale, q_slot0=q_slot0, gt=gt, n_tree=n_tree,
-                                   bitmask=bitmask)
-
     @staticmethod
     def _emit(samples, out, branch, out_off, out_base=None):
         o = _np(out)

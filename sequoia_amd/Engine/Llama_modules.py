@@ -10,18 +10,12 @@ tensor-parallel shards; tree forwards of <= 128 rows run Engine/ts_linear.py ins
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass
 
 import torch
 import torch.nn.functional as F
 
 from ..ops import get_ops
-
-# Fused RoPE + KV write + attention launch (sq_rope_tree_attention_f16): bit-identical to the two-kernel
-# path but measured slower on the 7B verify shape (13.6 us vs 8.4 + 2.5 us: every workgroup rotates the new
-# keys it reads and the strided qkv rows load worse than cache rows) and a tie on draft levels -> opt-in.
-FUSE_ROPE_ATTENTION = os.environ.get("SEQUOIA_FUSE_ROPE", "0") == "1"
 
 
 def rope_tables(head_dim: int, max_pos: int, base: float, device, dtype=torch.float16):
@@ -73,11 +67,6 @@ def attention_core(qkv, layer_idx: int, dims, kv_cache, cos, sin, position_ids, 
     attn = torch.empty(ops.frag_shape(q_len, n_heads * d) if out_frag else (q_len, n_heads * d), dtype=dt, device=dev)
     scale = 1.0 / math.sqrt(d)
     frag_kw = dict(out_frag=True) if out_frag else {}
-    if tree is not None and tree.contiguous_slots and FUSE_ROPE_ATTENTION and not out_frag and qkv_slab is None:
-        # one launch: RoPE of q and the new k, KV slot write, tree attention
-        ops.rope_tree_attention(qkv, k_layer, v_layer, cos, sin, position_ids, attn, n_heads, h_kv, d, tree.kv_len,
-                                scale, tree.q_slot0, tree.gt, tree.n_tree, tree.bitmask, ctx=tree.ctx)
-        return attn
     q_rot = torch.empty((n_heads, q_len, d), dtype=dt, device=dev)
     if qkv_slab is not None:
         ops.rope_kv_write_slabs(qkv_slab[0], qkv_slab[1], (n_heads + 2 * h_kv) * d, q_rot, k_layer, v_layer, cos, sin,

@@ -44,29 +44,7 @@ struct AttnParams {
     const uint64_t* bitmask;
     int words;
     const int32_t* ctx;     // optional device override of {q_slot0, gt, kv_len} (hipGraph replays)
-    // fused RoPE + KV write (ROPE kernels): the q_len new tokens occupy slots [q_slot0, q_slot0 + q_len) ==
-    // [kv_len - q_len, kv_len); q / k / v of the new tokens come from the packed projection output
-    const half_t* qkv;      // [q_len][qkv_stride] = q | k | v
-    int qkv_stride;
-    const half_t* cos_tab;  // [max_pos][D]
-    const half_t* sin_tab;
-    const int64_t* pos;     // [q_len] position of every new token
 };
-
-// RoPE of one 8-element fragment with the reference's fp16 rounding after every op
-// (q*cos + rotate_half(q)*sin, Engine/offload_engine.py:63-66): first half pairs with -x[d + D/2],
-// second half with +x[d - D/2]; both fragments of a pair live in the same lane.
-__device__ __forceinline__ half8 rope_frag(half8 x, half8 partner, half8 c, half8 sn, bool first_half) {
-    half8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const half_t a = (half_t)((float)x[j] * (float)c[j]);
-        const half_t pj = first_half ? (half_t)(-partner[j]) : partner[j];
-        const half_t b = (half_t)((float)pj * (float)sn[j]);
-        o[j] = (half_t)((float)a + (float)b);
-    }
-    return o;
-}
 
 // max / sum over the four 16-lane groups holding the same query (lanes l, l^16, l^32, l^48) with the
 // gfx950 VALU lane swaps (v_permlane16_swap / v_permlane32_swap) instead of LDS-routed ds_bpermute
@@ -97,11 +75,10 @@ __device__ __forceinline__ float group4_sum(float v) {
 
 // MASK: 0 = dense additive mask, 1 = tree mask with the bitmask row in two registers (n <= 128),
 // 2 = tree mask with the bitmask rows staged in LDS (n <= 512).
-// ROPE: fused apply_rotary_pos_emb + update_kv_cache + attention.  Every workgroup rotates the new keys it
-// needs itself (they are read from the projection output, so there is no dependency on another workgroup's
-// cache write); the workgroup of query tile 0 of the first query head of each KV head also writes the
-// rotated K rows and the V rows into their cache slots.
-template <int D, int MASK, bool ROPE>
+// (A variant that also applied RoPE and wrote the new K/V rows -- one launch instead of sq_rope_kv_write_f16 + this
+// kernel -- was bit-identical but slower on every measured shape: 13.6 vs 8.4 + 2.5 us on the 7B verify layer, 256 VGPRs
+// with spills; removed in round 2.)
+template <int D, int MASK>
 __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams P) {
     if (P.ctx) {   // uniform: step-dependent scalars live in device memory so the launch is graph-replayable
         P.q_slot0 = P.ctx[0]; P.gt = P.ctx[1]; P.kv_len = P.ctx[2];
@@ -147,10 +124,6 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
     const int kvh = head / grp;
     const half_t* kbase = P.k + (size_t)kvh * P.m * D;
     const half_t* vbase = P.v + (size_t)kvh * P.m * D;
-    const int new_start = P.q_slot0;                                    // ROPE: first slot of the new tokens
-    const bool writer = ROPE && q0 == 0 && (head % grp) == 0;            // writes this KV head's new rows
-    const half_t* qkv_k = ROPE ? P.qkv + (size_t)(P.n_heads + kvh) * D : nullptr;
-    const half_t* qkv_v = ROPE ? P.qkv + (size_t)(P.n_heads + P.h_kv + kvh) * D : nullptr;
 
     // this lane's query row (softmax side): q0 + qc
     const int qi = q0 + qc;
@@ -183,19 +156,7 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
 
     // Q fragments (B operand): lane (n = qc, g) holds Q[qi][32*s + 8*g .. +8]
     half8 qf[DSTEPS];
-    if constexpr (ROPE) {
-        const half_t* qrow = P.qkv + (size_t)qi_c * P.qkv_stride + (size_t)head * D;
-        const int64_t qpos = P.pos[qi_c];
-        half8 raw[DSTEPS];
-#pragma unroll
-        for (int s = 0; s < DSTEPS; ++s) raw[s] = *(const half8*)(qrow + s * 32 + g * 8);
-#pragma unroll
-        for (int s = 0; s < DSTEPS; ++s) {
-            const half8 c = *(const half8*)(P.cos_tab + (size_t)qpos * D + s * 32 + g * 8);
-            const half8 sn = *(const half8*)(P.sin_tab + (size_t)qpos * D + s * 32 + g * 8);
-            qf[s] = rope_frag(raw[s], raw[s ^ (DSTEPS / 2)], c, sn, s < DSTEPS / 2);
-        }
-    } else {
+    {
         const half_t* qrow = P.q + ((size_t)head * P.q_len + qi_c) * D;
 #pragma unroll
         for (int s = 0; s < DSTEPS; ++s) qf[s] = *(const half8*)(qrow + s * 32 + g * 8);
@@ -228,14 +189,8 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
             const int idx = it * 64 + lane;
             const int r = idx / CPR, c = idx % CPR;
             int row = key0 + r; if (row >= P.kv_len) row = P.kv_len - 1;
-            if (ROPE && row >= new_start) {            // new token: raw k / v straight from the projection output
-                const size_t off = (size_t)(row - new_start) * P.qkv_stride + c * 8;
-                kr[it] = *(const u32x4*)(qkv_k + off);
-                vr[it] = *(const u32x4*)(qkv_v + off);
-            } else {
-                kr[it] = *(const u32x4*)(kbase + (size_t)row * D + c * 8);
-                vr[it] = *(const u32x4*)(vbase + (size_t)row * D + c * 8);
-            }
+            kr[it] = *(const u32x4*)(kbase + (size_t)row * D + c * 8);
+            vr[it] = *(const u32x4*)(vbase + (size_t)row * D + c * 8);
         }
     };
 
@@ -251,11 +206,6 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
             const int idx = it * 64 + lane;
             *(u32x4*)(my_k + (idx / CPR) * VSTRIDE + (idx % CPR) * 8) = kr_cur[it];
             *(u32x4*)(my_v + (idx / CPR) * VSTRIDE + (idx % CPR) * 8) = vr_cur[it];
-            if (ROPE && writer) {                      // V rows of new tokens go to their cache slots unchanged
-                const int row = key0 + idx / CPR;
-                if (row >= new_start && row < P.kv_len)
-                    *(u32x4*)(const_cast<half_t*>(vbase) + (size_t)row * D + (idx % CPR) * 8) = vr_cur[it];
-            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -268,32 +218,6 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
             half8 kf[DSTEPS];
 #pragma unroll
             for (int s = 0; s < DSTEPS; ++s) kf[s] = *(const half8*)(my_k + (t * 16 + qc) * VSTRIDE + s * 32 + g * 8);
-            if constexpr (ROPE) {
-                const int krow = key0 + t * 16 + qc;              // this lane's key row
-                if (key0 + t * 16 + 15 >= new_start) {            // wave-uniform: the tile touches new tokens
-                    const bool is_new = krow >= new_start && krow < P.kv_len;
-                    const int64_t kpos = P.pos[is_new ? krow - new_start : 0];
-                    // one (d, d + D/2) fragment pair at a time keeps the live register set small
-#pragma unroll
-                    for (int sp = 0; sp < DSTEPS / 2; ++sp) {
-                        const int s1 = sp, s2 = sp + DSTEPS / 2;
-                        const half8 c1 = *(const half8*)(P.cos_tab + (size_t)kpos * D + s1 * 32 + g * 8);
-                        const half8 n1 = *(const half8*)(P.sin_tab + (size_t)kpos * D + s1 * 32 + g * 8);
-                        const half8 c2 = *(const half8*)(P.cos_tab + (size_t)kpos * D + s2 * 32 + g * 8);
-                        const half8 n2 = *(const half8*)(P.sin_tab + (size_t)kpos * D + s2 * 32 + g * 8);
-                        const half8 r1 = rope_frag(kf[s1], kf[s2], c1, n1, true);
-                        const half8 r2 = rope_frag(kf[s2], kf[s1], c2, n2, false);
-                        if (is_new) {
-                            kf[s1] = r1; kf[s2] = r2;
-                            if (writer) {
-                                *(half8*)(const_cast<half_t*>(kbase) + (size_t)krow * D + s1 * 32 + g * 8) = r1;
-                                *(half8*)(const_cast<half_t*>(kbase) + (size_t)krow * D + s2 * 32 + g * 8) = r2;
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
 #pragma unroll
             for (int s = 0; s < DSTEPS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[s], qf[s], acc, 0, 0, 0);
             s_acc[t] = acc;
@@ -463,45 +387,9 @@ extern "C" int sq_tree_attention_f16(const void* q, const void* k_layer, const v
     dim3 grid(slots * n_tiles), block(ATT_THREADS);
     hipStream_t st = (hipStream_t)stream;
     const int mk = mask_mode == 0 ? 0 : (P.words <= 2 ? 1 : 2);
-#define SQ_ATT(DD, MM) hipLaunchKernelGGL((tree_attention_kernel<DD, MM, false>), grid, block, 0, st, P)
+#define SQ_ATT(DD, MM) hipLaunchKernelGGL((tree_attention_kernel<DD, MM>), grid, block, 0, st, P)
     if (d == 128) { if (mk == 0) SQ_ATT(128, 0); else if (mk == 1) SQ_ATT(128, 1); else SQ_ATT(128, 2); }
     else          { if (mk == 0) SQ_ATT(64, 0);  else if (mk == 1) SQ_ATT(64, 1);  else SQ_ATT(64, 2); }
 #undef SQ_ATT
-    return sq_check_launch();
-}
-
-extern "C" int sq_rope_tree_attention_f16(const void* qkv, int qkv_stride, void* k_layer, void* v_layer,
-                                          const void* cos_tab, const void* sin_tab, const int64_t* d_position_ids,
-                                          void* out, int q_len, int n_heads, int h_kv, int d, int m, int kv_len,
-                                          float scale, int q_slot0, int gt, int n_tree, const uint64_t* d_bitmask,
-                                          int words, const int32_t* d_ctx, void* stream) {
-    if (!qkv || !k_layer || !v_layer || !cos_tab || !sin_tab || !d_position_ids || !out) return SQ_EINVAL;
-    if (q_len < 0 || n_heads <= 0 || h_kv <= 0 || m <= 0 || n_heads % h_kv) return SQ_EINVAL;
-    if (qkv_stride < (n_heads + 2 * h_kv) * d || (qkv_stride & 7)) return SQ_EINVAL;
-    if (d_ctx) { if (kv_len <= 0) kv_len = q_len > 0 ? q_len : 1; if (gt < 1) gt = 1; if (q_slot0 < 0) q_slot0 = 0; }
-    else if (kv_len != q_slot0 + q_len) return SQ_EINVAL;   // the new tokens are the last q_len slots
-    if (kv_len <= 0 || kv_len > m || gt < 1 || n_tree < 1 || n_tree > SQ_MAX_TREE) return SQ_EINVAL;
-    if (n_tree > 1 && (!d_bitmask || words < SQ_MASK_WORDS(n_tree) || words > SQ_MAX_TREE / 64)) return SQ_EINVAL;
-    if (d != 64 && d != 128) return SQ_EUNSUPPORTED;
-    if (q_len == 0) return SQ_OK;
-    AttnParams P;
-    P.out_frag_mtp = 0;
-    P.q = nullptr; P.k = (const half_t*)k_layer; P.v = (const half_t*)v_layer; P.out = (half_t*)out;
-    P.q_len = q_len; P.n_heads = n_heads; P.h_kv = h_kv; P.m = m; P.kv_len = kv_len;
-    P.scale_log2e = scale * 1.4426950408889634f;
-    P.mask_mode = 1; P.dense = nullptr; P.mask_stride = 0;
-    P.q_slot0 = q_slot0; P.gt = gt; P.n_tree = n_tree; P.bitmask = d_bitmask; P.words = n_tree == 1 ? (words > 0 ? words : 1) : words;
-    P.ctx = d_ctx;
-    P.qkv = (const half_t*)qkv; P.qkv_stride = qkv_stride; P.cos_tab = (const half_t*)cos_tab;
-    P.sin_tab = (const half_t*)sin_tab; P.pos = d_position_ids;
-    const int n_tiles = (q_len + ATT_BM - 1) / ATT_BM;
-    const int slots = h_kv >= 8 ? 8 * ((h_kv + 7) / 8) * (n_heads / h_kv) : 8 * ((n_heads + 7) / 8);
-    dim3 grid(slots * n_tiles), block(ATT_THREADS);
-    hipStream_t st = (hipStream_t)stream;
-    const bool regs = P.words <= 2;
-#define SQ_ATTR(DD, MM) hipLaunchKernelGGL((tree_attention_kernel<DD, MM, true>), grid, block, 0, st, P)
-    if (d == 128) { if (regs) SQ_ATTR(128, 1); else SQ_ATTR(128, 2); }
-    else          { if (regs) SQ_ATTR(64, 1);  else SQ_ATTR(64, 2); }
-#undef SQ_ATTR
     return sq_check_launch();
 }

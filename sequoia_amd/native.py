@@ -38,8 +38,6 @@ PROTOTYPES = {
     "sq_rope_kv_write_slabs_f16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_tree_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _i, _i, _i,
                                    _vp, _i, _vp, _vp]),
-    "sq_rope_tree_attention_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i,
-                                        _vp, _i, _vp, _vp]),
     "sq_store_i32": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "sq_sample_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "sq_logits_stats_f16": (_i, [_vp, _i64, _vp, _i, _i, _f, _vp, _i, _vp, _i64, _vp]),

@@ -169,25 +169,6 @@ class HipOps:
         check(rc, "sq_tree_attention_f16")
         return out
 
-    def rope_tree_attention(self, qkv, k_layer, v_layer, cos, sin, position_ids, out, n_heads, h_kv, d, kv_len, scale,
-                            q_slot0, gt, n_tree, bitmask, ctx=None):
-        """Fused RoPE + KV write + tree attention; new tokens sit at slots [q_slot0, q_slot0 + q_len)."""
-        _need(qkv, torch.float16, "qkv", contiguous=False)
-        assert qkv.dim() == 2 and qkv.stride(1) == 1
-        _need(k_layer, torch.float16, "k_layer"); _need(v_layer, torch.float16, "v_layer"); _need(out, torch.float16, "out")
-        _need(cos, torch.float16, "cos"); _need(sin, torch.float16, "sin"); _need(position_ids, torch.int64, "position_ids")
-        words = 0
-        if bitmask is not None:
-            _need(bitmask, torch.int64, "bitmask")
-            words = bitmask.shape[1]
-        m = k_layer.shape[-2]
-        check(self.lib.sq_rope_tree_attention_f16(qkv.data_ptr(), qkv.stride(0), k_layer.data_ptr(), v_layer.data_ptr(),
-                                                  cos.data_ptr(), sin.data_ptr(), position_ids.data_ptr(), out.data_ptr(),
-                                                  qkv.shape[0], n_heads, h_kv, d, m, kv_len, scale, q_slot0, gt, n_tree,
-                                                  _ptr(bitmask), words, _ptr(ctx), self._stream()),
-              "sq_rope_tree_attention_f16")
-        return out
-
     # ---- a2 ---------------------------------------------------------------------------------
     def _sample_ws(self, device, n_rows, vocab, k):
         """Sampler scratch, one buffer per device, grown outside graph captures (sized generously on first use)."""

@@ -438,38 +438,6 @@ def test_top_p_filter(ops, V, gain, top_p):
             assert (np.isinf(d.cpu().numpy()) != np.isinf(z[f"wor{i}/topp09"])).sum(axis=1).max() <= 6
 
 
-@pytest.mark.parametrize("H,Hkv,D,M,gt,n,q_slot0,q_len", [
-    (12, 12, 64, 384, 128, 128, 147, 34),    # draft level
-    (32, 32, 128, 384, 129, 128, 128, 128),  # 7B verify
-    (8, 2, 128, 256, 40, 65, 0, 104),        # GQA, prefill + tree in one call (all rows new)
-    (64, 8, 128, 512, 300, 129, 299, 129),   # 70B head layout on one GPU
-    (4, 4, 64, 96, 12, 4, 11, 1),            # single token
-])
-def test_fused_rope_attention_equals_two_kernel_path(ops, H, Hkv, D, M, gt, n, q_slot0, q_len):
-    """sq_rope_tree_attention_f16 == sq_rope_kv_write_f16 + sq_tree_attention_f16, bit for bit: same
-    attention output, same K/V bytes in the cache slots."""
-    rng = np.random.RandomState(H + q_len)
-    succ = random_tree(rng, n)
-    bm = dev(O.bitmask_from_successors(succ).view(np.int64))
-    kv_len = q_slot0 + q_len
-    cos, sin = O.rope_tables(D, 512)
-    qkv = dev(rng.randn(q_len, (H + 2 * Hkv) * D).astype(np.float16))
-    pos = dev(rng.randint(0, 512, size=q_len).astype(np.int64))
-    sid = torch.arange(q_slot0, kv_len, device=DEV)
-    k0 = rng.randn(Hkv, M, D).astype(np.float16); v0 = rng.randn(Hkv, M, D).astype(np.float16)
-    ka, va, kb, vb = dev(k0), dev(v0), dev(k0), dev(v0)
-    dcos, dsin = dev(cos), dev(sin)
-    scale = D ** -0.5
-    q_rot = torch.empty(H, q_len, D, dtype=torch.float16, device=DEV)
-    out_a = torch.empty(q_len, H * D, dtype=torch.float16, device=DEV)
-    ops.rope_kv_write(qkv, q_rot, ka, va, dcos, dsin, pos, sid, H, Hkv, D)
-    ops.tree_attention(q_rot, ka, va, out_a, kv_len, scale, q_slot0=q_slot0, gt=gt, n_tree=n, bitmask=bm)
-    out_b = torch.empty_like(out_a)
-    ops.rope_tree_attention(qkv, kb, vb, dcos, dsin, pos, out_b, H, Hkv, D, kv_len, scale, q_slot0, gt, n, bm)
-    assert torch.equal(ka, kb) and torch.equal(va, vb)
-    assert torch.equal(out_a, out_b)
-
-
 @pytest.mark.parametrize("H,Hkv,D,q,splits", [(4, 4, 64, 7, 2), (32, 32, 128, 128, 2), (8, 1, 128, 129, 3)])
 def test_rope_kv_write_from_split_k_slabs(ops, H, Hkv, D, q, splits):
     """sq_rope_kv_write_slabs_f16 == sq_rope_kv_write_f16 on h(sum of the partials in split order), bit for bit."""

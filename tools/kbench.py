@@ -65,7 +65,7 @@ if what in ("attn", "all"):
         t = timeit(f, 320)
         byts = 2 * Hkv * kv_len * D * 2 + 2 * H * qn * D * 2
         out["attn_" + name] = dict(us=round(t, 2), GBps=round(byts / t / 1e3, 1), MB=round(byts / 1e6, 2))
-        # separate rope+kv write, and the fused rope+attention launch
+        # the RoPE + KV write launch that precedes it
         qkv = torch.randn(qn, (H + 2 * Hkv) * D, device=dev).half()
         cos = torch.randn(2048, D, device=dev).half()
         pos = torch.arange(q_slot0, q_slot0 + qn, device=dev)
@@ -76,13 +76,7 @@ if what in ("attn", "all"):
             li[0] += 1
             ops.rope_kv_write(qkv, qr, kc[l], vc[l], cos, cos, pos, pos, H, Hkv, D)
 
-        def f_fused():
-            l = li[0] % L
-            li[0] += 1
-            ops.rope_tree_attention(qkv, kc[l], vc[l], cos, cos, pos, o, H, Hkv, D, kv_len, D ** -0.5, q_slot0, gt, n,
-                                    gd["bitmask"])
         out["rope_" + name] = dict(us=round(timeit(f_rope, 320), 2))
-        out["fused_rope_attn_" + name] = dict(us=round(timeit(f_fused, 320), 2))
 if what in ("samp", "all"):
     dl = (torch.randn(n, V, device=dev) * 3).half()
     rand = torch.rand(n, V, device=dev).half()
