@@ -54,6 +54,8 @@ __device__ __forceinline__ half_t grid_sum_to_f16(unsigned long long total) {
 
 // Correctly rounded a / b for a wave-uniform divisor: the refined reciprocal is computed once, every quotient costs one
 // multiply and two fused multiply-adds (same result as div_rn for finite a).
+// (packed fp32 forms of the quotient -- v_pk_mul_f32 / v_pk_fma_f32 on pairs -- measured slower here: 129 vs 110 us on the
+// all-rejected tree)
 struct RcpDiv {
     float b, r;
     __device__ __forceinline__ explicit RcpDiv(float b_) : b(b_) {
@@ -68,6 +70,13 @@ struct RcpDiv {
         // last fma (v_fma_mixlo_f16: one rounding of the exact fma result), which differs near fp16 ties.
         asm volatile("" : "+v"(q));
         return q;
+    }
+};
+        const float2v q0 = a * rv;
+        float2v q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, bb, a), rv, q0);
+        float qa = q[0], qb = q[1];
+        asm volatile("" : "+v"(qa), "+v"(qb));
+        return float2v{qa, qb};
     }
 };
 
@@ -238,6 +247,7 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
     __shared__ float s_s[VER_WAVES];
     __shared__ unsigned long long s_u[VER_WAVES];
     __shared__ float s_tok[2];            // e[tok], p[tok] of the child under test
+    __shared__ floatx4 s_e4[(EPT / 4) * VER_THREADS];     // the draft row's exponentials (128 KB at V <= 32768)
     const int t = threadIdx.x;
     const int node = blockIdx.x;
     const VerifyWs ws = ws_layout(ws_raw, n_tree);
@@ -252,9 +262,10 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
     float sf = 1.0f;                      // normaliser of p: 1 = p holds probabilities, else p holds relu(p - q) and sf its sum
     bool scaled = false;
     if (nc > 0) {
-        // draft side: e = exp(y - mx) with y = h(x / T); a rejected token gets e = 0 and its bit in `masked` (the row is
-        // re-read from L2 only when the maximum itself is rejected and the exponentials have to be rebased)
-        float e[EPT];
+        // draft side: e = exp(y - mx) with y = h(x / T), kept in LDS ([EPT / 4][thread] float4 columns: thread-private,
+        // conflict-free 16-byte accesses) -- 32 fewer live registers than a register array, and the rejected token's entry
+        // is addressed directly instead of through a 32-way select.  A rejected token gets e = 0 and its bit in `masked`
+        // (the row is re-read from L2 only when the maximum itself is rejected and the exponentials are rebased).
         uint32_t masked = 0u;
         const half_t* xd = draft_logits + (size_t)node * vocab;
         const RcpDiv div_t(temperature);
@@ -276,11 +287,21 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             }
             return lmax;
         };
-        float mx = block_max_f32<VER_WAVES>(load_y(e), s_f);
-        float lsum = 0.f;
+        float mx, z;
+        auto rebase = [&]() {             // e <- exp(y - max y), z <- sum e
+            float y[EPT];
+            mx = block_max_f32<VER_WAVES>(load_y(y), s_f);
+            float lsum = 0.f;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) { e[i] = exp_fast(e[i] - mx); lsum += e[i]; }
-        float z = block_sum_f32<VER_WAVES>(lsum, s_f);
+            for (int k4 = 0; k4 < EPT / 4; ++k4) {
+                floatx4 ev;
+#pragma unroll
+                for (int h4 = 0; h4 < 4; ++h4) { ev[h4] = exp_fast(y[4 * k4 + h4] - mx); lsum += ev[h4]; }
+                s_e4[k4 * VER_THREADS + t] = ev;
+            }
+            z = block_sum_f32<VER_WAVES>(lsum, s_f);
+        };
+        rebase();
 
         for (int jc = 0; jc < nc; ++jc) {
             const int child = child_ids[c0 + jc];
@@ -289,16 +310,16 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             const float rr = (RULE == 2) ? ((const float*)r_raw)[slot] : (float)((const half_t*)r_raw)[slot];
             // element tok lives in thread (tok/8) % THREADS at register (tok/8/THREADS)*8 + tok%8:
             // a scalar index compare instead of 32 per-thread element ids held in registers
-            const bool mine = t == ((tok >> 3) & (VER_THREADS - 1));
-            const int tok_local = ((tok >> 3) / VER_THREADS) * 8 + (tok & 7);
+            const bool tok_ok = tok >= 0 && tok < vocab;
+            const bool mine = tok_ok && t == ((tok >> 3) & (VER_THREADS - 1));
+            const int tok_local = tok_ok ? ((tok >> 3) / VER_THREADS) * 8 + (tok & 7) : 0;
+            float* e_tok_ptr = (float*)&s_e4[(tok_local >> 2) * VER_THREADS + t] + (tok_local & 3);
             const RcpDiv div_sf(sf), div_z(z);
             // broadcast e[tok], p[tok] from the owning thread
+            if (mine) s_tok[0] = *e_tok_ptr;
 #pragma unroll
             for (int i = 0; i < EPT; ++i)
-                if (mine && i == tok_local) {
-                    s_tok[0] = e[i];
-                    s_tok[1] = scaled ? (float)(half_t)div_sf((float)H2(p, i)) : (float)H2(p, i);
-                }
+                if (mine && i == tok_local) s_tok[1] = scaled ? (float)(half_t)div_sf((float)H2(p, i)) : (float)H2(p, i);
             __syncthreads();
             const float e_tok = s_tok[0];
             const half_t q_tok = (half_t)div_z(e_tok);
@@ -310,30 +331,35 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
                 const half_t rq = (half_t)(rr * (float)q_tok);
                 ok = REPLACE ? (p_tok >= rq) : (p_tok > rq);                  // Tree/SpecTree.py:152 (strict)
             }
-            ok = ok && (tok >= 0 && tok < vocab);
+            ok = ok && tok_ok;
             if (ok) { accepted = child; break; }
             // reject: p <- relu(p - q) / sum(relu(p - q));  draft_logits[tok] <- -65504 (=> q[tok] = 0)
             uint32_t lint = 0u;
             float nsum = 0.f;
             const half2v zero2 = {(half_t)0.0f, (half_t)0.0f};
 #pragma unroll
-            for (int k2 = 0; k2 < EPT / 2; ++k2) {
-                half2v pi = p[k2];
-                if (scaled) { pi[0] = (half_t)div_sf((float)pi[0]); pi[1] = (half_t)div_sf((float)pi[1]); }
-                half2v q;
-                q[0] = (half_t)div_z(e[2 * k2]); q[1] = (half_t)div_z(e[2 * k2 + 1]);
-                // relu_(p - q) in packed fp16 (one rounding, like the reference's fp16 tensor op); a NaN difference
-                // becomes 0 (max returns the number), as `d > 0 ? d : 0` did
-                const half2v di = __builtin_elementwise_max(pi - q, zero2);
-                p[k2] = di;                                      // p now holds the unnormalised residual
-                lint += (uint32_t)((float)di[0] * 16777216.0f) + (uint32_t)((float)di[1] * 16777216.0f);
+            for (int k4 = 0; k4 < EPT / 4; ++k4) {
+                const floatx4 ev = s_e4[k4 * VER_THREADS + t];
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
-                    const int i = 2 * k2 + h2;
-                    if (!REPLACE && mine && i == tok_local) { e[i] = 0.f; masked |= 1u << i; }
-                    nsum += e[i];                                // fresh sum of the draft without the rejected token
+                    const int k2 = 2 * k4 + h2;
+                    half2v pi = p[k2];
+                    if (scaled) { pi[0] = (half_t)div_sf((float)pi[0]); pi[1] = (half_t)div_sf((float)pi[1]); }
+                    half2v q;
+                    q[0] = (half_t)div_z(ev[2 * h2]); q[1] = (half_t)div_z(ev[2 * h2 + 1]);
+                    // relu_(p - q) in packed fp16 (one rounding, like the reference's fp16 tensor op); a NaN difference
+                    // becomes 0 (max returns the number), as `d > 0 ? d : 0` did
+                    const half2v di = __builtin_elementwise_max(pi - q, zero2);
+                    p[k2] = di;                                  // p now holds the unnormalised residual
+                    lint += (uint32_t)((float)di[0] * 16777216.0f) + (uint32_t)((float)di[1] * 16777216.0f);
+#pragma unroll
+                    for (int h1 = 0; h1 < 2; ++h1) {             // fresh sum of the draft without the rejected token
+                        const int i = 2 * k2 + h1;
+                        nsum += (!REPLACE && mine && i == tok_local) ? 0.f : ev[2 * h2 + h1];
+                    }
                 }
             }
+            if (!REPLACE && mine) { *e_tok_ptr = 0.f; masked |= 1u << tok_local; }
             const Red3 red = block_red3(lint, 0.f, nsum, s_u, s_m, s_s);   // also orders the s_tok reads above
             if (red.isum == 0ull) nan_flag = 1;                  // 0/0 -> NaN residual (utils.py:7)
             sf = (float)grid_sum_to_f16(red.isum);
@@ -342,13 +368,7 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             if (nan_flag) break;          // every later comparison with NaN is false: all rejected
             if (REPLACE) continue;        // q is unchanged
             z = red.fsum;
-            if (e_tok == 1.0f) {          // the rejected token sat at the maximum (exp(0) is exactly 1): rebase the
-                mx = block_max_f32<VER_WAVES>(load_y(e), s_f);   // exponentials on the maximum of what is left
-                lsum = 0.f;
-#pragma unroll
-                for (int i = 0; i < EPT; ++i) { e[i] = exp_fast(e[i] - mx); lsum += e[i]; }
-                z = block_sum_f32<VER_WAVES>(lsum, s_f);
-            }
+            if (e_tok == 1.0f) rebase();  // the rejected token sat at the maximum (exp(0) is exactly 1)
         }
         if (nan_flag) nrej = nc;
     }

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/r2/tests6.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r2/tests6.log
-grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/r2/tests6.log | tail -20
+timeout 200 python tools/kbench.py verify 2>&1 | tail -5
+timeout 600 python -m pytest tests/test_hip_kernels.py tests/test_e2e_gpu.py tests/test_properties_gpu.py tests/test_probe_gpu.py -q 2>&1 | tail -3

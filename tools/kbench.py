@@ -11,6 +11,7 @@ from sequoia_amd.growmap import GrowMap  # noqa: E402
 from sequoia_amd.ops import get_ops  # noqa: E402
 
 dev = "cuda:0"
+torch.manual_seed(0)
 ops = get_ops()
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 
@@ -93,17 +94,32 @@ if what in ("samp", "all"):
     out["topk_rows19_k8"] = dict(us=round(timeit(f, 100), 2))
 if what in ("verify", "all"):
     tl = (torch.randn(n, V, device=dev) * 3).half()
-    dl = (tl.float() + torch.randn(n, V, device=dev) * 2).half()
-    toks = torch.randint(3, V, (M,), device=dev)
     r = torch.rand(M, device=dev).half()
+    rand = torch.rand(n, V, device=dev).half()
     ws = ops.verify_workspace(n, dev)
     rr = torch.zeros(64 + n, dtype=torch.int32, device=dev)
-
-    def f():
-        ops.verify_stochastic(tl, dl, toks, r, gd["child_off"], gd["child_ids"], n, 160, 0.6, 12345, ws, rr)
-    t = timeit(f, 50)
     n_int = sum(1 for s in g.successors if s)
-    out["verify_stochastic"] = dict(us=round(t, 2), GBps=round((n + n_int) * V * 2 / t / 1e3, 1))
+    gt0 = 160
+    # draft quality scenarios; the tree's tokens are SAMPLED from the draft rows (level by level, like the loop), so the
+    # accept / reject pattern is the algorithm's, not that of random token ids
+    for name, mix, noise in (("independent_draft", 0.0, 3.0), ("poor_draft", 1.0, 2.0), ("good_draft", 1.0, 0.5), ("identical", 1.0, 0.0)):
+        dl0 = (tl.float() * mix + torch.randn(n, V, device=dev) * noise).half()
+        toks = torch.randint(3, V, (M,), device=dev)
+        for lv in gd["levels"]:
+            ops.sample_wor(dl0, rand, lv["row_ids"], lv["k"], 0.6, toks[gt0 + lv["first_child"] - 1:], branch=lv["branch"],
+                           out_off=lv["out_off"])
+        dl = dl0.clone()
+
+        def f(dl=dl, dl0=dl0, toks=toks):
+            dl.copy_(dl0)                      # the verifier writes -65504 into rejected entries
+            ops.verify_stochastic(tl, dl, toks, r, gd["child_off"], gd["child_ids"], n, gt0, 0.6, 12345, ws, rr)
+
+        def f_copy(dl=dl, dl0=dl0):
+            dl.copy_(dl0)
+        t = timeit(f, 50) - timeit(f_copy, 50)
+        torch.cuda.synchronize()
+        res = rr.cpu()
+        out["verify_stochastic_" + name] = dict(us=round(t, 2), GBps=round((n + n_int) * V * 2 / t / 1e3, 1), accepted=int(res[1]))
 
     def f2():
         ops.verify_greedy(tl, toks, gd["child_off"], gd["child_ids"], n, 160, ws, rr)
