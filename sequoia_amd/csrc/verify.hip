@@ -72,13 +72,6 @@ struct RcpDiv {
         return q;
     }
 };
-        const float2v q0 = a * rv;
-        float2v q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, bb, a), rv, q0);
-        float qa = q[0], qb = q[1];
-        asm volatile("" : "+v"(qa), "+v"(qb));
-        return float2v{qa, qb};
-    }
-};
 
 // softmax(x / T) with the reference's rounding: returns h(exp(y - max) / sum) per element (y = h(x / T)).  The
 // exponentials stay in registers between the sum pass and the normalisation (the array is dead afterwards).
