@@ -19,6 +19,9 @@
 #define PART_CH 2                                  // 16-byte chunks per thread
 #define PART_ELEMS (PART_THREADS * PART_CH * 8)    // 4096
 #define SAMP_MAX_PARTS 32                          // vocab <= 131072
+#define SAMP_FAST_K 32                             // threshold selection + counting ranks up to this many samples per row
+#define SAMP_WAVE_CAP 64                           // candidate slots per wave on that path
+#define SAMP_RANK_MAX 512                          // candidates the counting merge orders (parts x samples)
 
 __host__ __device__ static inline int samp_parts(int vocab) { return (vocab + PART_ELEMS - 1) / PART_ELEMS; }
 
@@ -75,26 +78,30 @@ logits_stats_kernel(const half_t* __restrict__ logits, int64_t ld, const int32_t
     }
 }
 
-// row statistics from the per-part ones, identical in every consumer: M = max m_p, z = sum_p s_p exp(m_p - M) in part order
+// row statistics from the per-part ones, identical in every consumer: M = max m_p, z = sum_p s_p exp(m_p - M) in part order.
+// Lane p of every wave loads part p's pair (ONE memory round trip instead of a dependent load per part), the maximum is a
+// wave reduction, the sum runs over the lanes' terms in part order (v_readlane, no memory).
 __device__ __forceinline__ void combine_stats(const float* __restrict__ st, int parts, float& M, float& z) {
-    float mx = -INFINITY;
-    for (int q = 0; q < parts; ++q) mx = fmaxf(mx, st[q * 2]);
+    const int lane = threadIdx.x & 63;
+    float m = -INFINITY, sm = 0.f;
+    if (lane < parts) { m = st[lane * 2]; sm = st[lane * 2 + 1]; }
+    const float mx = wave_max_f32_dpp(m);
+    const float term = (m > -INFINITY) ? sm * exp_fast(m - mx) : 0.f;
     float acc = 0.f;
-    for (int q = 0; q < parts; ++q) {
-        const float mq = st[q * 2];
-        if (mq > -INFINITY) acc += st[q * 2 + 1] * exp_fast(mq - mx);
-    }
+    for (int q = 0; q < parts; ++q) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), q));
     M = mx; z = acc;
 }
 
 // ---- 2. keys + local top-k of one part -----------------------------------------------------------------------------
 template <typename C> struct Comp;
 template <> struct Comp<uint32_t> {
+    typedef uint16_t key_t;
     static __device__ __forceinline__ uint32_t make(uint32_t ord, int e) { return (ord << 16) | (0xffffu - (uint32_t)e); }
     static __device__ __forceinline__ int64_t id(uint32_t c) { return (int64_t)(0xffffu - (c & 0xffffu)); }
     static __device__ __forceinline__ uint32_t wave_max(uint32_t v) { return wave_max_u32_dpp(v); }
 };
 template <> struct Comp<unsigned long long> {
+    typedef uint32_t key_t;
     static __device__ __forceinline__ unsigned long long make(uint32_t ord, int e) {
         return ((unsigned long long)(ord + 1u) << 32) | (uint32_t)(0xffffffffu - (uint32_t)e);
     }
@@ -148,7 +155,7 @@ sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const 
                     const float* __restrict__ stats, int stats_by_source_row, const int32_t* __restrict__ branch,
                     C* __restrict__ cand) {
     constexpr int EPT = PART_CH * 8;
-    __shared__ C s_cand[PART_WAVES * SQ_MAX_TOPK];
+    __shared__ __attribute__((aligned(16))) C s_cand[PART_WAVES * SQ_MAX_TOPK];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = blockIdx.x, p = blockIdx.y, parts = gridDim.y;
     int n_out = k;
@@ -227,7 +234,66 @@ sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const 
             for (int j = 0; j < 8; ++j) comp[c * 8 + j] = (e0 < vocab) ? Comp<C>::make(f16_to_ordered(v[j]), e0 + j) : (C)0;
         }
     }
-    // level 1: every wave extracts its own top-n_out (no barriers); level 2: wave 0 merges the 4 lists
+    C* dst = cand + ((size_t)r * parts + p) * k;
+    if (n_out <= SAMP_FAST_K) {
+        // Threshold selection: the n_out-th largest of the 64 lane maxima bounds the wave's n_out-th largest element from
+        // below, so every element of the wave's top n_out has a key >= that bound.  The bound is found by bisection on the
+        // key bits (one ballot + popcount per step, no data movement), the few elements at or above it are compacted
+        // into LDS with ballot prefixes, and the workgroup's candidates (about n_out per wave) are ordered by counting,
+        // for each candidate, how many are larger -- no k-round arg-max chain anywhere.
+        constexpr int KB = sizeof(C) * 4;                           // key bits = the composite's upper half
+        typedef typename Comp<C>::key_t K;
+        C lmax = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) lmax = comp[i] > lmax ? comp[i] : lmax;
+        const K lkey = (K)(lmax >> KB);
+        K lo = 0, hi = (K)~(K)0;                                    // largest key t with #{lanes: lkey >= t} >= n_out
+        if (__builtin_popcountll(__ballot(lmax != 0)) < n_out) {
+            hi = 0;                                                 // fewer live lanes than requested: everything qualifies
+        } else {
+            while (lo < hi) {
+                const K mid = lo + ((hi - lo) >> 1) + 1;
+                if (__builtin_popcountll(__ballot(lkey >= mid)) >= n_out) lo = mid; else hi = (K)(mid - 1);
+            }
+        }
+        const K tau = hi;
+        int base = 0;
+        C* seg = s_cand + wave * SAMP_WAVE_CAP;
+        seg[lane] = 0;                                              // unused slots read as "nothing" (SAMP_WAVE_CAP == 64)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const bool take = comp[i] != 0 && (K)(comp[i] >> KB) >= tau;
+            const unsigned long long b = __ballot(take);
+            const int pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (take && pos < SAMP_WAVE_CAP) seg[pos] = comp[i];
+            base += __builtin_popcountll(b);
+        }
+        if (base > SAMP_WAVE_CAP) {                                 // many equal keys: the exact arg-max rounds for this wave
+            seg[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            wave_topk<C, EPT>(comp, EPT, n_out, lane, [&](int s2, C win) { seg[s2] = win; });
+        }
+        __syncthreads();
+        // order by counting: thread t owns slot t of the 4 x 64 slots; its output position is the number of larger
+        // candidates.  Fixed-length scans with wide LDS reads: no dependent load per candidate.
+        const C mine = s_cand[t];
+        int rank = 0, live = 0;
+        constexpr int VEC = 16 / sizeof(C);
+        typedef C cvec __attribute__((ext_vector_type(VEC)));
+#pragma unroll 8
+        for (int j = 0; j < PART_WAVES * SAMP_WAVE_CAP / VEC; ++j) {
+            const cvec v = ((const cvec*)s_cand)[j];                  // same address in every lane: LDS broadcast
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { rank += v[e] > mine; live += v[e] != 0; }
+        }
+        if (mine != 0 && rank < n_out) dst[rank] = mine;
+        if (t >= live && t < n_out) dst[t] = 0;                     // fewer live candidates than requested
+        return;
+    }
+    // more than SAMP_FAST_K samples per row: k rounds of arg-max per wave, then wave 0 merges the 4 lists
     wave_topk<C, EPT>(comp, EPT, n_out, lane, [&](int s, C win) { s_cand[wave * SQ_MAX_TOPK + s] = win; });
     __syncthreads();
     if (wave == 0) {
@@ -239,12 +305,59 @@ sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const 
             const int idx = j * 64 + lane;                     // (wave w, rank s) = (idx / n_out, idx % n_out)
             c[j] = idx < total ? s_cand[(idx / n_out) * SQ_MAX_TOPK + (idx % n_out)] : (C)0;
         }
-        C* dst = cand + ((size_t)r * parts + p) * k;
         wave_topk<C, CPL>(c, (total + 63) >> 6, n_out, lane, [&](int s, C win) { dst[s] = win; });
     }
 }
 
-// ---- 3. merge the parts' candidate lists, one wave per row ----------------------------------------------------------
+// ---- 3. merge the parts' candidate lists ---------------------------------------------------------------------------
+// parts x n_out <= SAMP_RANK_MAX candidates: one 256-thread workgroup per row orders them by counting (a candidate's output
+// position is the number of larger candidates); otherwise one wave per row runs k arg-max rounds.
+template <typename C>
+__global__ void __launch_bounds__(256)
+sample_merge_rank_kernel(const C* __restrict__ cand, int parts, int k, int64_t* __restrict__ out,
+                         const int32_t* __restrict__ branch, const int32_t* __restrict__ out_off,
+                         const int32_t* __restrict__ out_base) {
+    __shared__ __attribute__((aligned(16))) C s_all[SAMP_RANK_MAX];
+    const int r = blockIdx.x, t = threadIdx.x;
+    int n_out = k;
+    int64_t* dst = out + (int64_t)r * k;
+    if (branch) {
+        n_out = branch[r];
+        if (n_out > k) n_out = k;
+        dst = out + out_off[r];
+    }
+    if (out_base) dst += *out_base;
+    if (n_out <= 0) return;
+    const C* src = cand + (size_t)r * parts * k;
+    const int total = parts * n_out;
+    constexpr int VEC = 16 / sizeof(C);
+    typedef C cvec __attribute__((ext_vector_type(VEC)));
+    const int padded = (total + 4 * VEC - 1) / (4 * VEC) * (4 * VEC);          // zero padding: "nothing"
+    for (int idx = t; idx < padded; idx += 256) s_all[idx] = idx < total ? src[(size_t)(idx / n_out) * k + (idx % n_out)] : (C)0;
+    __syncthreads();
+    C mine[SAMP_RANK_MAX / 256];
+    int rank[SAMP_RANK_MAX / 256], live = 0;
+#pragma unroll
+    for (int u = 0; u < SAMP_RANK_MAX / 256; ++u) { mine[u] = (t + u * 256 < total) ? s_all[t + u * 256] : (C)0; rank[u] = 0; }
+    for (int j = 0; j < padded / VEC; j += 4) {
+        cvec v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ((const cvec*)s_all)[j + q];           // same address in every lane: broadcast
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                live += v[q][e] != 0;
+#pragma unroll
+                for (int u = 0; u < SAMP_RANK_MAX / 256; ++u) rank[u] += v[q][e] > mine[u];
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < SAMP_RANK_MAX / 256; ++u)
+        if (mine[u] != 0 && rank[u] < n_out) dst[rank[u]] = Comp<C>::id(mine[u]);
+    if (t >= live && t < n_out) dst[t] = 0;
+}
+
 template <typename C, int CPL>
 __global__ void __launch_bounds__(64)
 sample_merge_kernel(const C* __restrict__ cand, int parts, int k, int64_t* __restrict__ out,
@@ -293,6 +406,11 @@ static int launch_sampler(const void* logits, int64_t ld_logits, const void* rnd
                        cand);
     int rc = sq_check_launch();
     if (rc != SQ_OK) return rc;
+    if (parts * k <= SAMP_RANK_MAX && k <= SAMP_FAST_K) {
+        hipLaunchKernelGGL((sample_merge_rank_kernel<C>), dim3(n_rows), dim3(256), 0, st, (const C*)cand, parts, k, out, branch,
+                           out_off, out_base);
+        return sq_check_launch();
+    }
 #define SQ_MERGE(CPL) hipLaunchKernelGGL((sample_merge_kernel<C, CPL>), dim3(n_rows), dim3(64), 0, st, (const C*)cand, parts, \
                                          k, out, branch, out_off, out_base)
     if (parts * k <= 64 * 4) SQ_MERGE(4);
