@@ -317,34 +317,29 @@ class NativeTree(Tree):
     def enqueue_step(self):
         st, p = self.state, self._pipe
         idx = p["next_idx"]
+        slot = idx % SQ_RESULT_RING
+        st.ring_np[slot, 7] = -1                 # the walker stores the step index here LAST: the record's arrival flag
         st.launch()
-        if st.cuda:
-            ev = torch.cuda.Event()
-            ev.record()
-            slot = idx % st.host_ring.shape[0]
-            with torch.cuda.stream(st.copy_stream):
-                st.copy_stream.wait_event(ev)
-                st.host_ring[slot].copy_(st.ring[slot * SQ_RESULT_INTS:(slot + 1) * SQ_RESULT_INTS], non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-            p["inflight"].append((idx, done))
-        else:
-            p["inflight"].append((idx, None))
+        p["inflight"].append(idx)
         p["next_idx"] = idx + 1
 
-    def collect_step(self):
-        """Result of the oldest step in flight: (accept_length, n_accepted, bonus_token, terminal).  Blocks only until
-        that step's 256-byte record has reached the host (the copy runs beside the following step)."""
+    def collect_step(self, timeout_s: float = 30.0):
+        """Result of the oldest step in flight: (accept_length, n_accepted, bonus_token, terminal).  Polls that step's
+        256-byte record in pinned host memory: it arrives when the step's verification is done, while the step's KV
+        compaction and next-root forward (and the following step, if enqueued) are still running."""
         st, p = self.state, self._pipe
-        idx, done = p["inflight"].popleft()
-        slot = idx % SQ_RESULT_RING
-        if done is not None:
-            done.synchronize()
-            rec = st.host_ring[slot]
-        else:
-            rec = st.ring[slot * SQ_RESULT_INTS:(slot + 1) * SQ_RESULT_INTS]
+        idx = p["inflight"].popleft()
+        rec = st.ring_np[idx % SQ_RESULT_RING]
+        if st.cuda:
+            t0 = time.time()
+            spins = 0
+            while int(rec[7]) != idx:
+                spins += 1
+                if (spins & 0xfff) == 0 and time.time() - t0 > timeout_s:
+                    raise RuntimeError(f"step {idx}: no result record after {timeout_s} s")
+        rec = rec.copy()
         a, n_acc, bonus, terminal = int(rec[SQ_RES_ACCEPT_LEN]), int(rec[SQ_RES_N_TREE]), int(rec[2]), bool(rec[SQ_RES_TERMINAL])
-        assert int(rec[7]) == idx, f"result ring slot {slot} holds step {int(rec[7])}, expected {idx}"
+        assert int(rec[7]) == idx, f"result ring slot {idx % SQ_RESULT_RING} holds step {int(rec[7])}, expected {idx}"
         self.last_result = rec
         self.step_idx = idx + 1
         if terminal:
@@ -375,6 +370,8 @@ class NativeTree(Tree):
             return
         while p["inflight"]:
             self.collect_step()
+        if self.state.cuda:
+            torch.cuda.current_stream().synchronize()      # a record arrives before its step's tail (compaction, next root)
         gt, n = self.ground_truth_len, self.tree_size
         self.position_ids[:gt] = self._arange[:gt]
         if gt + n - 1 <= self.max_length:

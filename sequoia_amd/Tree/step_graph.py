@@ -3,8 +3,8 @@
 step.  The ground-truth length lives in a device block (include/sequoia_hip.h, SQ_STEP_*): the samplers, the input
 staging of every forward, the verifier, both KV compactions and the 1-token draft forward read it there, the verifier
 writes the next one.  On a HIP device the sequence is captured once per (engines, growmap, sampling parameters) into a
-hipGraph and replayed per step; the host reads each step's 256-byte result record from a ring, one step late, through
-a copy stream -- the GPU never waits for the host inside or between steps.
+hipGraph and replayed per step; the verifier writes each step's 256-byte result record into a ring in pinned host
+memory, which the host polls one step late -- the GPU never waits for the host inside or between steps.
 
 The static buffers (tokens, draft logits, noise, step block, staging buffers) belong to a StepState that outlives the
 per-prompt tree objects of the harness: a new tree adopts them (per-prompt constructor, outside the timed region).
@@ -67,18 +67,20 @@ class StepState:
         self.step = torch.zeros(SQ_STEP_INTS, dtype=torch.int32, device=dev)
         self.bonus = torch.zeros(N_BONUS, dtype=torch.int32, device=dev)
         self.result = torch.zeros(SQ_RESULT_INTS + n, dtype=torch.int32, device=dev)
-        self.ring = torch.zeros(SQ_RESULT_RING * SQ_RESULT_INTS, dtype=torch.int32, device=dev)
+        self.cuda = str(dev).startswith("cuda")
+        # result ring: pinned host memory on a HIP device -- the walker writes each step's record straight into it and the
+        # host polls the record's step-index word (no copy, no event wait: an event wait costs about a millisecond of
+        # wake-up latency per step on this runtime)
+        self.ring = torch.zeros(SQ_RESULT_RING * SQ_RESULT_INTS, dtype=torch.int32, device="cpu" if self.cuda else dev)
+        if self.cuda:
+            self.ring = self.ring.pin_memory()
+        self.ring_np = self.ring.numpy().reshape(SQ_RESULT_RING, SQ_RESULT_INTS) if self.ring.device.type == "cpu" else None
         self.verify_ws = self.ops.verify_workspace(n, dev)
         bm = self.gdev["bitmask"]
         self.fwd_levels = [_Fwd(lv["total"], n, bm, dev) for lv in self.gdev["levels"]]
         self.fwd_target = _Fwd(n, n, bm, dev)
         self.fwd_one = _Fwd(1, n, bm, dev)
         self.graph = None
-        self.cuda = str(dev).startswith("cuda")
-        if self.cuda:
-            self.copy_stream = torch.cuda.Stream(device=dev)
-            self.host_ring = torch.zeros((SQ_RESULT_RING, SQ_RESULT_INTS), dtype=torch.int32).pin_memory()
-            self.events = [None] * SQ_RESULT_RING
 
     # ---- the launch sequence of one step --------------------------------------------------------------------
     def body(self):

@@ -464,9 +464,15 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, int to
         // device-driven step: the next step starts at new_gt = a + 1 (the bonus token is committed at slot a)
         d_step[SQ_STEP_NEXT_GT] = terminal ? gt : a + 1;
         if (terminal) d_step[SQ_STEP_ACTIVE] = 0;
-        if (d_ring) {                                                 // copy of the header for the host, one slot per step
+        if (d_ring) {
+            // copy of the header for the host, one slot per step.  The ring may live in pinned host memory (the host then
+            // polls it instead of waiting on an event): everything but the step-index word first, a system-scope fence,
+            // then the index word -- a reader that sees the index sees the record.
             int32_t* slot = d_ring + ((uint32_t)d_step[SQ_STEP_INDEX] % SQ_RESULT_RING) * SQ_RESULT_INTS;
-            for (int i = 0; i < SQ_RESULT_INTS; ++i) slot[i] = result[i];
+            for (int i = 0; i < SQ_RESULT_INTS; ++i)
+                if (i != 7) slot[i] = result[i];
+            __threadfence_system();
+            __hip_atomic_store(slot + 7, result[7], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -11,6 +11,8 @@ import time
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
+# whole-step graphs kept in flight by the device-driven loop (the result ring has SQ_RESULT_RING = 4 slots)
+PIPE_DEPTH = max(1, min(3, int(os.environ.get("SEQUOIA_PIPE_DEPTH", "2"))))
 
 
 def _sync(device):
@@ -118,7 +120,7 @@ class Loop:
             while done < k_steps and self.tree is not None:
                 if piped and tree._pipe is not None:
                     # device-driven: keep up to two whole-step graphs in flight, read results one step late
-                    while (len(tree._pipe["inflight"]) < 2 and tree.can_enqueue(self.max_new)
+                    while (len(tree._pipe["inflight"]) < PIPE_DEPTH and tree.can_enqueue(self.max_new)
                            and done + len(tree._pipe["inflight"]) < k_steps):
                         tree.enqueue_step()
                     if not tree._pipe["inflight"]:

@@ -268,6 +268,14 @@ class HipOps:
         nbytes = int(self.lib.sq_verify_workspace_bytes(n_tree))
         return torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)
 
+    @staticmethod
+    def _check_ring(ring):
+        """The result ring is device memory or PINNED host memory (device-accessible: the walker writes the record where
+        the host polls it)."""
+        if ring.dtype != torch.int32 or not ring.is_contiguous() or not (ring.device.type == "cuda" or ring.is_pinned()):
+            raise TypeError("result_ring: contiguous int32 tensor on the device or in pinned host memory")
+        assert ring.numel() >= native.SQ_RESULT_RING * native.SQ_RESULT_INTS
+
     def verify_stochastic(self, target_logits, draft_logits, tokens, r, child_off, child_ids, n_tree, gt, temperature,
                           u24, workspace, result, step=None, bonus_table=None, result_ring=None):
         """step / bonus_table / result_ring: the device-driven form (gt and the bonus uniform read on the device)."""
@@ -281,8 +289,7 @@ class HipOps:
         if bonus_table is not None:
             _need(bonus_table, torch.int32, "bonus_table")
         if result_ring is not None:
-            _need(result_ring, torch.int32, "result_ring")
-            assert result_ring.numel() >= native.SQ_RESULT_RING * native.SQ_RESULT_INTS
+            self._check_ring(result_ring)
         check(self.lib.sq_verify_stochastic_f16(target_logits.data_ptr(), draft_logits.data_ptr(), tokens.data_ptr(),
                                                 tokens.numel(), r.data_ptr(), child_off.data_ptr(), _ptr(child_ids), n_tree,
                                                 vocab, int(gt), float(temperature), int(u24), workspace.data_ptr(),
@@ -343,7 +350,7 @@ class HipOps:
         if step is not None:
             _need(step, torch.int32, "step")
         if result_ring is not None:
-            _need(result_ring, torch.int32, "result_ring")
+            self._check_ring(result_ring)
         check(self.lib.sq_verify_greedy_f16(target_logits.data_ptr(), tokens.data_ptr(), tokens.numel(), child_off.data_ptr(),
                                             _ptr(child_ids), n_tree, vocab, int(gt), workspace.data_ptr(), result.data_ptr(),
                                             _ptr(step), _ptr(result_ring), self._stream()), "sq_verify_greedy_f16")

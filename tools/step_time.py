@@ -50,3 +50,43 @@ for mode in ("sync", "piped"):
         loop.run_steps(N)
         torch.cuda.synchronize()
         print(f"device-driven harness : {(time.perf_counter() - t0) / N * 1e3:.3f} ms/step (wall, {N} steps)")
+        # host timeline of the pipelined loop: enqueue / collect durations per step (two steps in flight)
+        torch.manual_seed(17)
+        draft.clear_kv(); target.clear_kv()
+        loop = Loop(cfg, draft, target, gm, dev, prompts, pipelined=True)
+        loop.run_steps(1)
+        tree = loop.tree
+        tree.begin_pipeline()
+        torch.cuda.synchronize()
+        enq, col = [], []
+        t_start = time.perf_counter()
+        tree.enqueue_step()
+        for i in range(N):
+            t0 = time.perf_counter()
+            tree.enqueue_step()
+            t1 = time.perf_counter()
+            tree.collect_step()
+            t2 = time.perf_counter()
+            enq.append((t1 - t0) * 1e3); col.append((t2 - t1) * 1e3)
+        tree.collect_step()
+        torch.cuda.synchronize()
+        total = (time.perf_counter() - t_start) / (N + 1) * 1e3
+        print(f"timeline              : {total:.3f} ms/step; enqueue ms {[round(x, 2) for x in enq[:6]]}, collect ms {[round(x, 2) for x in col[:6]]}")
+        # the same graph, one launch + device synchronisation per step (no events, no copy stream)
+        torch.manual_seed(17)
+        draft.clear_kv(); target.clear_kv()
+        loop = Loop(cfg, draft, target, gm, dev, prompts, pipelined=True)
+        loop.run_steps(1)
+        tree = loop.tree
+        tree.begin_pipeline()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(N):
+            tree.state.launch()
+            torch.cuda.synchronize()
+        print(f"launch + synchronize  : {(time.perf_counter() - t0) / N * 1e3:.3f} ms/step")
+        t0 = time.perf_counter()
+        for i in range(N // 2):
+            tree.state.launch(); tree.state.launch()
+            torch.cuda.synchronize()
+        print(f"2 launches + sync     : {(time.perf_counter() - t0) / (N // 2 * 2) * 1e3:.3f} ms/step")
