@@ -31,6 +31,13 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Compile-time experiment switches (-DTS_DBG=bits, tools/ts_dbg_build.sh): 1 = activations from one k-step (L1 hits),
+// 2 = weights likewise, 4 = no MFMA, 8 = no loads in the loop, 16 = no prologue loads, 32 = no merge / stores.
+// They must not be run-time branches: a conditional around the loads makes the
+// compiler drain vmcnt at the join and the kernel loses a third of its speed (measured).
+#ifndef TS_DBG
+#define TS_DBG 0
+#endif
 #define TS_WAVES 4
 #define TS_THREADS (TS_WAVES * 64)
 #define TS_MAXM 144              // 9 row tiles: the 129-node 64x2 tree of the 70B configuration
@@ -42,8 +49,8 @@ struct TsParams {
     half_t* out;          // [M][ldo] row-major, or fragment-major [n_out/32][mtp][64][8]   (splits == 1)
     float* slab;          // [splits][M][n_out] fp32                                         (splits > 1)
     int m, mtp, n_out, k, ldo, splits, tiles, units, out_frag;
-    int dbg;              // experiment switches (SQ_TS_DEBUG): 1 = activations from one k-step (L1 hits), 2 = weights likewise
 };
+
 
 // row tiles per merge pass: 4 wave images of [16 MH][16 NT + 4] fp32 must fit 150 KB of LDS
 constexpr int ts_merge_tiles(int mt, int nt) {
@@ -82,8 +89,8 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) aoff[mt] = (uint32_t)min(mt, P.mtp - 1) * 1024u + (uint32_t)lane * 16u;
-    const uint32_t a_step = (P.dbg & 1) ? 0u : (uint32_t)P.mtp * 1024u;
-    const uint32_t w_shift = (P.dbg & 2) ? 31u : 10u;
+    const uint32_t a_step = (TS_DBG & 1) ? 0u : (uint32_t)P.mtp * 1024u;
+    const uint32_t w_shift = (TS_DBG & 2) ? 31u : 10u;
     const char* wbase = (const char*)P.w;
     const char* abase = (const char*)P.a;
 
@@ -116,14 +123,20 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
                 acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[d][mt], wr[d][t], acc[mt][t], 0, 0, 0); \
     }
 #pragma unroll
-        for (int d = 0; d < D; ++d) TS_LOAD(d, TS_KS(min(d, nst - 1)));
+        for (int d = 0; d < D; ++d) {
+            if (!(TS_DBG & 16)) { TS_LOAD(d, TS_KS(min(d, nst - 1))); }
+            else {
+                _Pragma("unroll") for (int t = 0; t < NT; ++t) wr[d][t] = half8{1, 1, 1, 1, 1, 1, 1, 1};
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ar[d][mt] = half8{1, 1, 1, 1, 1, 1, 1, 1};
+            }
+        }
         const int nfull = nst / D, rem = nst - nfull * D;
         int i = 0;
         for (int it = 0; it < nfull; ++it, i += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                if (!(P.dbg & 4)) TS_MMA(d);
-                if (!(P.dbg & 8)) TS_LOAD(d, TS_KS(min(i + D + d, nst - 1)));   // refill the stage just consumed (clamped at the end)
+                if (!(TS_DBG & 4)) TS_MMA(d);
+                if (!(TS_DBG & 8)) TS_LOAD(d, TS_KS(min(i + D + d, nst - 1)));   // refill the stage just consumed (clamped at the end)
                 __builtin_amdgcn_sched_barrier(0);           // keep the stages in ring order (no cross-stage MFMA interleave)
             }
         }
@@ -138,6 +151,15 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
     // ---- the 4 wave partials meet in LDS: image[wave][row][col], MFMA C layout row = 16 mt + 4 g + i; MH row tiles per
     //      pass so that the four images fit the CU's LDS (one pass except for the widest tiles) --------------------
     constexpr int MH = ts_merge_tiles(MT, NT);
+    if (TS_DBG & 32) {                                         // experiment: no merge, no stores (keeps the accumulators live)
+        float sacc = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) sacc += acc[mt][t][0] + acc[mt][t][1] + acc[mt][t][2] + acc[mt][t][3];
+        if (sacc == 12345.678f) P.out[tid] = (half_t)sacc;
+        return;
+    }
     const int groups = nu * 2;                                 // output items: (row, 8-column group); a unit holds 2
     for (int m0 = 0; m0 < MT; m0 += MH) {
         if (m0 > 0) __syncthreads();                           // the previous pass has been read out
@@ -205,6 +227,7 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
     }
 }
 
+
 extern "C" size_t sq_linear_ts_workspace_bytes(int m, int n_out, int splits) {
     return splits > 1 ? (size_t)splits * m * n_out * sizeof(float) : 0;
 }
@@ -261,7 +284,6 @@ extern "C" int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const vo
     P.slab = (float*)slab;
     P.m = m; P.mtp = (m + 15) / 16; P.n_out = n_out; P.k = k; P.ldo = ldo; P.splits = splits; P.out_frag = out_frag;
     P.units = n_out / 16;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SQ_TS_DEBUG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
     P.tiles = tiles > P.units ? P.units : tiles;
     if (splits > 1) {
         if (silu || res || out_frag) return SQ_EUNSUPPORTED;   // the slab consumer applies the epilogue
@@ -271,7 +293,7 @@ extern "C" int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const vo
     const int max_units = (P.units + P.tiles - 1) / P.tiles;
     const int nt = max_units * (silu ? 2 : 1);
     hipStream_t st = (hipStream_t)stream;
-    int rc;
+    int rc = SQ_OK;
     const int mt = P.mtp;                                    // row tiles; 5 and 7 run on the 6 / 8 builds (tiles alias)
     if (mt <= 1) rc = ts_dispatch<1>(P, silu, nt, st);
     else if (mt == 2) rc = ts_dispatch<2>(P, silu, nt, st);

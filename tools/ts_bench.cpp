@@ -71,6 +71,16 @@ int main(int argc, char** argv) {
                 }
             for (int t : {256, 512}) if (!sh.silu || true) { if ((units + t - 1) / t <= max_u && units >= t) cands.push_back({t, 1}); }
             if (getenv("TS_TILES") && getenv("TS_SPLITS")) { cands.clear(); cands.push_back({atoi(getenv("TS_TILES")), atoi(getenv("TS_SPLITS"))}); }
+            if (const char* cs = getenv("TS_CANDS")) {          // explicit list: "64x4,96x2,..."
+                cands.clear();
+                for (const char* q = cs; *q;) {
+                    int t = 0, sp = 0, used = 0;
+                    if (sscanf(q, "%dx%d%n", &t, &sp, &used) != 2) break;
+                    cands.push_back({t, sp});
+                    q += used;
+                    if (*q == ',') ++q;
+                }
+            }
             for (auto [tiles, splits] : cands) {
                 const size_t need = sq_linear_ts_workspace_bytes(m, sh.n_out, splits);
                 if (need > slab_cap) continue;
