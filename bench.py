@@ -167,6 +167,9 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
     from sequoia_amd import ops as ops_mod
     prev = ops_mod._OPS
     ops_mod.set_ops_for_testing(OracleOps() if numpy_ops else TorchCpuOps())     # numpy_ops: the checking oracle (slow)
+    # fp16 CPU GEMMs of <= 255 rows do not scale past a few dozen threads (128 threads: 13 s / step, 8 threads: 3.3 s)
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(prev_threads, int(os.environ.get("SEQUOIA_CPU_THREADS", "32")))))
     try:
         t0 = time.perf_counter()
         draft, target, gm = engines if engines is not None else build(cfg, "cpu", pair)
@@ -203,6 +206,7 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
                     step_seconds=[round(x, 3) for x in step_s], step_tokens=step_tok, tokens=valid[:cur].tolist())
     finally:
         ops_mod.set_ops_for_testing(prev)
+        torch.set_num_threads(prev_threads)
 
 
 def spawn_ranks(n: int) -> int:
