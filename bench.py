@@ -229,18 +229,28 @@ def tp_extra(n: int, args) -> dict:
     the same N GPUs (RCCL all-reduce over xGMI), as a CHILD job with a timeout -- a stuck collective cannot take the
     headline line with it.  Returns the child's JSON line (trimmed) or an error record."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--config", "E", "--steps", str(min(args.steps, 24)),
-           "--warmup", "2", "--no-cpu-baseline", "--no-autoregressive", "--no-tuned-growmap", "--no-tp-extra", "--sync-loop"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--config", "E", "--steps", str(min(args.steps, 12)),
+           "--warmup", "2", "--no-cpu-baseline", "--no-autoregressive", "--no-tuned-growmap", "--no-tp-extra", "--sync-loop",
+           "--backend", args.backend]
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
                         "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
                         "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
     env["SEQUOIA_TS_EXCLUSIVE"] = "1"          # one copy of the 70B shard per rank
+    import signal
+    from types import SimpleNamespace
+    # own session: on a timeout the whole tree (launcher + ranks) is killed by process group, nothing keeps a GPU
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=int(os.environ.get("SEQUOIA_TP_EXTRA_TIMEOUT", "420")),
-                             env=env)
+        so, se = proc.communicate(timeout=int(os.environ.get("SEQUOIA_TP_EXTRA_TIMEOUT", "300")))
     except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.communicate()
         return dict(error="timeout")
+    out = SimpleNamespace(stdout=so, stderr=se, returncode=proc.returncode)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if out.returncode != 0 or not lines:
         return dict(error=f"rc {out.returncode}", stderr=out.stderr[-400:])
@@ -304,6 +314,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SEQUOIA_BENCH_ONE_DEVICE", "0") == "1":
+        local = 0              # test rig: every rank on GPU 0 (with --backend gloo) to run the N > 1 code paths on a 1-GPU box
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     if world > 1:
@@ -323,7 +335,8 @@ def main():
     if args.growmap:
         cfg["growmap"] = args.growmap
     gemm_tuned = False
-    if not args.no_gemm_tuning:
+    if not args.no_gemm_tuning and not (cfg.get("tp") and world > 1):      # TP: per-rank TunableOp picks would make the
+        #                                                                     replicated draft differ between ranks
         from sequoia_amd import gemm_tuning
         gemm_tuned = gemm_tuning.enable()
     draft, target, gm = build(cfg, device, args.pair)

@@ -50,9 +50,9 @@ class _TPInner(InferenceEngineTG):
         q, v = logits.shape
         logits = logits.contiguous()
         if logits.device.type == "cuda":
-            out = torch.empty((self.world, q, v), dtype=logits.dtype, device=logits.device)
-            dist.all_gather_into_tensor(out, logits, group=self.group)
-            return out.permute(1, 0, 2).reshape(q, self.world * v)
+            out = torch.empty((self.world * q, v), dtype=logits.dtype, device=logits.device)   # rank-major rows (the
+            dist.all_gather_into_tensor(out, logits, group=self.group)                         # shape every backend takes)
+            return out.view(self.world, q, v).permute(1, 0, 2).reshape(q, self.world * v)
         parts = [torch.empty_like(logits) for _ in range(self.world)]
         dist.all_gather(parts, logits, group=self.group)
         return torch.cat(parts, dim=-1)

@@ -31,6 +31,11 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLAN_FILE = os.path.join(_PKG, "ts_plans_gfx950.json")
 MAX_ROWS = 144
 ENABLED = os.environ.get("SEQUOIA_TS_LINEAR", "1") != "0"
+# Tensor-parallel jobs replicate the draft model, the samplers and the verifier on every rank and rely on bit-identical
+# results across ranks (no broadcast of decisions).  Launch plans picked by per-rank timing would break that (a
+# different split order changes the last bit of a logit), so with this flag a shape without a shipped plan takes the
+# deterministic default plan (lm_head: the PyTorch GEMM) instead of being timed.  Set by harness.build for TP configs.
+DETERMINISTIC_PLANS = os.environ.get("SEQUOIA_TS_DETERMINISTIC", "0") == "1"
 
 _SHIPPED = None
 
@@ -183,6 +188,8 @@ class TsLinearSet:
                     #                        of a graph runner come first and cache the real plan)
                 elif rec != "torch" and not have_images and not self._images_fit(name):
                     rec = "torch"
+                elif rec is None and DETERMINISTIC_PLANS:
+                    rec = "torch" if name == "lm_head" else self.default_plan(name, q_len)
                 elif rec is None:
                     rec = self.autotune(name, q_len)
                 p[name] = None if rec == "torch" else (int(rec[0]), int(rec[1]))

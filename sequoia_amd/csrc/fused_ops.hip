@@ -251,6 +251,15 @@ silu_mul_kernel(const half_t* __restrict__ gate_up, half_t* __restrict__ out, in
     const size_t row = blockIdx.y;
     const int c = blockIdx.x * ROW_THREADS + threadIdx.x;
     if (c * 8 >= inter) return;
+    if (inter & 7) {      // odd widths (a tensor-parallel shard of a toy model): element-wise, same arithmetic
+        const half_t* g = gate_up + row * 2 * inter;
+        for (int j = c * 8; j < min(inter, c * 8 + 8); ++j) {
+            const float gf = (float)g[j];
+            const half_t sv = (half_t)(gf / (1.0f + expf(-gf)));
+            out[row * inter + j] = (half_t)((float)sv * (float)g[inter + j]);
+        }
+        return;
+    }
     const half8 gv = *(const half8*)(gate_up + row * 2 * inter + c * 8);
     const half8 uv = *(const half8*)(gate_up + row * 2 * inter + inter + c * 8);
     half8 o;
@@ -265,9 +274,8 @@ silu_mul_kernel(const half_t* __restrict__ gate_up, half_t* __restrict__ out, in
 
 extern "C" int sq_silu_mul_f16(const void* gate_up, void* out, int rows, int inter, void* stream) {
     if (!gate_up || !out || rows < 0 || inter <= 0) return SQ_EINVAL;
-    if (inter & 7) return SQ_EUNSUPPORTED;
     if (rows == 0) return SQ_OK;
-    const int chunks = inter >> 3;
+    const int chunks = (inter + 7) >> 3;
     hipLaunchKernelGGL(silu_mul_kernel, dim3((chunks + ROW_THREADS - 1) / ROW_THREADS, rows), dim3(ROW_THREADS), 0,
                        (hipStream_t)stream, (const half_t*)gate_up, (half_t*)out, inter, 0);
     return sq_check_launch();

@@ -43,6 +43,9 @@ def build(cfg, device, pair, seed_d=1, seed_t=2):
     from sequoia_amd.Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
     from sequoia_amd.growmap import GrowMap
     M = cfg["M"]
+    if cfg.get("tp") and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from sequoia_amd.Engine import ts_linear
+        ts_linear.DETERMINISTIC_PLANS = True       # replicated decisions need identical arithmetic on every rank
     if pair == "calibrated":
         from sequoia_amd.synthetic import calibrated_pair_specs
         tpw = int(os.environ.get("WORLD_SIZE", "1")) if cfg.get("tp") else 1

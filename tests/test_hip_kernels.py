@@ -391,6 +391,12 @@ def test_rmsnorm_silu(ops):
     ops.silu_mul(gu, o)
     want = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
     assert (o.float() - want.float()).abs().max() < 4e-3
+    odd = 172                                   # a 2-way shard of the traces' MLP width (not a multiple of 8)
+    gu = torch.from_numpy(rng.randn(rows, 2 * odd).astype(np.float16)).to(DEV)
+    o = torch.full((rows, odd), float("nan"), dtype=torch.float16, device=DEV)
+    ops.silu_mul(gu, o)
+    want = torch.nn.functional.silu(gu[:, :odd]) * gu[:, odd:]
+    assert (o.float() - want.float()).abs().max() < 4e-3
 
 
 def test_verify_greedy_deep_chain(ops):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, name, out_dir):
+def _worker(rank, world, port, name, out_dir, device="cpu"):
     sys.path.insert(0, REPO); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -26,23 +26,24 @@ def _worker(rank, world, port, name, out_dir):
     from sequoia_amd import ops
     from sequoia_amd.Engine.Engine import GraphInferenceEngine
     from sequoia_amd.Engine.offload_engine import OffloadEngine
-    ops.set_ops_for_testing(OracleOps())
+    if device == "cpu":
+        ops.set_ops_for_testing(OracleOps())      # (on a GPU the HIP kernels run: tests/test_tp_world2_gpu.py)
     z, meta = load_trace(name)
     M = meta["M"]
     dspec = dict(state_dict=state_dict_of(z, "draft"), config=dims_dict(meta["draft_dims"], meta["vocab"]))
     tspec = dict(state_dict=state_dict_of(z, "target"), config=dims_dict(meta["target_dims"], meta["vocab"]))
-    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device="cpu")
-    target = OffloadEngine(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device="cpu")
+    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
+    target = OffloadEngine(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
     assert target.world == world and target.engine.kv_cache.k_cache.shape[2] == max(1, meta["target_dims"][4] // world)
-    tree = make_tree(z, meta, draft, target, "cpu")
+    tree = make_tree(z, meta, draft, target, device)
     steps = []
     for s in range(int(z["n_steps"])):
         tree.construct_grow_map()
-        tokens_pre = tree.tokens.numpy().copy()
-        dl = tree.draft_logits.float().numpy().copy()
+        tokens_pre = tree.tokens.cpu().numpy().copy()
+        dl = tree.draft_logits.float().cpu().numpy().copy()
         valid, a, _, term = tree.verify()
-        steps.append(dict(valid=valid.numpy().copy(), accept_len=int(a), terminal=bool(term), tokens_pre=tokens_pre,
-                          draft_logits=dl, target_logits=tree.target_logits.float().numpy().copy(),
+        steps.append(dict(valid=valid.cpu().numpy().copy(), accept_len=int(a), terminal=bool(term), tokens_pre=tokens_pre,
+                          draft_logits=dl, target_logits=tree.target_logits.float().cpu().numpy().copy(),
                           ref_valid=z[f"step{s}/valid_tokens"], ref_tokens_pre=z[f"step{s}/tokens_pre"],
                           ref_accept_len=int(z[f"step{s}/accept_len"]), gt=int(z[f"step{s}/gt"])))
     matched, diverged = check_replay(steps, z, meta)

@@ -1,10 +1,9 @@
 #!/bin/bash
+# N > 1 code paths on a one-GPU box: two ranks on GPU 0 over gloo -- (1) config E tensor-parallel at world 2 on the HIP
+# kernels, (2) two replicas of the default config + the tp_70b child job
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r2
-cp sequoia_amd/lib/libsequoia_hip.so /tmp/new.so
-for rep in 1 2; do
-for v in new old; do
-  if [ $v = old ]; then cp tools/_dbg/att_old/libsequoia_hip.so sequoia_amd/lib/libsequoia_hip.so; else cp /tmp/new.so sequoia_amd/lib/libsequoia_hip.so; fi
-  echo "== $v" ; timeout 300 python tools/kbench.py attn 2>&1 | grep attn_
-done; done | tee gpurun_out/r2/kbench_attn_ab.log
-cp /tmp/new.so sequoia_amd/lib/libsequoia_hip.so
+export SEQUOIA_BENCH_ONE_DEVICE=1
+echo "== TP world 2 (gloo, one device), config E" 
+SEQUOIA_TS_EXCLUSIVE=1 timeout 900 python bench.py --gpus 2 --backend gloo --config E --steps 6 --warmup 2 --no-cpu-baseline --no-autoregressive --no-tuned-growmap --no-tp-extra --sync-loop > gpurun_out/r2/tp2_gloo.json 2> gpurun_out/r2/tp2_gloo.err; echo "rc=$?"; tail -c 1200 gpurun_out/r2/tp2_gloo.json; tail -5 gpurun_out/r2/tp2_gloo.err
+
