@@ -154,6 +154,9 @@ def kernel_rooflines(cfg, loop, device):
     return res
 
 
+T_START = time.perf_counter()
+
+
 def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=False):
     """The CPU path timed on this box's host cores: the same host loop with the reference's PyTorch op sequences
     restated for CPU tensors (oracle/ops_torch_cpu.py; verification on the numpy oracle) and PyTorch CPU GEMMs, fp16
@@ -242,7 +245,7 @@ def tp_extra(n: int, args) -> dict:
     # own session: on a timeout the whole tree (launcher + ranks) is killed by process group, nothing keeps a GPU
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
     try:
-        so, se = proc.communicate(timeout=int(os.environ.get("SEQUOIA_TP_EXTRA_TIMEOUT", "300")))
+        so, se = proc.communicate(timeout=int(os.environ.get("SEQUOIA_TP_EXTRA_TIMEOUT", "240")))
     except subprocess.TimeoutExpired:
         try:
             os.killpg(proc.pid, signal.SIGKILL)
@@ -465,7 +468,11 @@ def main():
             del loop, draft, target
             torch.cuda.empty_cache()
             time.sleep(3.0)
-            line["tp_70b"] = tp_extra(world, args)
+            spent = time.perf_counter() - T_START
+            if spent > float(os.environ.get("SEQUOIA_TP_EXTRA_AFTER", "360")):
+                line["tp_70b"] = dict(error=f"skipped: {spent:.0f} s already spent on the replica run")
+            else:
+                line["tp_70b"] = tp_extra(world, args)
         print(json.dumps(line))
 
 

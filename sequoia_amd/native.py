@@ -86,6 +86,10 @@ def load() -> C.CDLL:
         raise SequoiaNativeError(
             f"{LIB_PATH} not found: build it with `python -m sequoia_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no non-HIP fallback")
+    # The library and PyTorch must share ONE HIP runtime (streams and device pointers cross the boundary): torch first,
+    # so that the library's libamdhip64 dependency resolves to the copy torch has already mapped.  Loaded the other way
+    # round the process holds two runtimes and sq_device_ready() reports no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         try:
