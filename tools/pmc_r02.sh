@@ -13,7 +13,7 @@ run_ts() {   # tag shape tiles splits
 }
 run_ts qkv qkv 128 2
 run_ts o "o+res" 64 4
-run_ts gate_up gate_up 230 1
+run_ts gate_up "gate_up+silu" 230 1
 run_ts down "down+res" 64 4
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
   tagp=$(echo $pass | cut -d' ' -f1)

@@ -47,12 +47,12 @@ K["gate_up@8:230x1"] = entry("ts_gate_up", "ts_linear_kernel<8, 6, 3, true>", 58
                              2 * 11008 * 4096 * 2 + M * 4096 * 2 + M * 11008 * 2)
 K["down@8:64x4"] = entry("ts_down", "ts_linear_kernel<8, 4, 3, false>", 65536, "7B down_proj 4096x11008, 128 rows, tiles 64 x splits 4",
                          4096 * 11008 * 2 + M * 11008 * 2 + 4 * M * 4096 * 4)
-K["tree_attention_target7b"] = entry("attn", "tree_attention_kernel<128, 1, false>", 131072,
+K["tree_attention_target7b"] = entry("attn", "tree_attention_kernel<128, 1>", 131072,
                                      "7B verify layer: H=32, q=128, kv_len=287, D=128, implicit tree mask",
                                      2 * 32 * 287 * 128 * 2 + 2 * 32 * 128 * 128 * 2)
-K["tree_attention_draft68m_level"] = entry("attn", "tree_attention_kernel<64, 1, false>", 24576, "68m draft level: H=12, q=34, kv_len=214, D=64",
+K["tree_attention_draft68m_level"] = entry("attn", "tree_attention_kernel<64, 1>", 24576, "68m draft level: H=12, q=34, kv_len=214, D=64",
                                            2 * 12 * 214 * 64 * 2 + 2 * 12 * 34 * 64 * 2)
-K["tree_attention_target70b_shard"] = entry("attn", "tree_attention_kernel<128, 1, false>", 36864, "70B shard (TP=8): H=8, H_kv=1, q=129, kv_len=288",
+K["tree_attention_target70b_shard"] = entry("attn", "tree_attention_kernel<128, 1>", 36864, "70B shard (TP=8): H=8, H_kv=1, q=129, kv_len=288",
                                             2 * 1 * 288 * 128 * 2 + 2 * 8 * 129 * 128 * 2)
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 for k, v in K.items():
