@@ -327,7 +327,7 @@ int sq_repack_rows_frag_f16(const void* x, int ldx, void* x_frag, int m, int k, 
 
 /* Tall-skinny linear layer of a tree forward (m <= 128 rows: one tree / tree level), nn.Linear semantics
  * out = a . w^T, fp32 accumulation, fp16 output -- the dense projections of LlamaAttention_FI/TG and LlamaMLP_FI
- * (Engine/Llama_modules.py:104-112,138,199-207,256,262-271) when q_len <= 128, as an HBM weight stream over
+ * (Engine/Llama_modules.py:104-112,138,199-207,256,262-271) when q_len <= 144, as an HBM weight stream over
  * fragment-major operands (above).  The launch has tiles x splits workgroups: the n_out / 16 column units are
  * partitioned over `tiles` workgroups (<= 4 units each; silu: <= 3), K over `splits`.
  *   splits == 1, silu != 0   : w_frag holds gate tiles [0, n_out/16) then up tiles;

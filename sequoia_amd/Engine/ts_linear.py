@@ -1,4 +1,4 @@
-"""Tall-skinny linear layers for tree forwards (q_len <= 128): weight images, launch plans, forward.
+"""Tall-skinny linear layers for tree forwards (q_len <= 144): weight images, launch plans, forward.
 
 The dense projections of a tree forward multiply <= 128 activation rows by every weight of the model — an
 HBM stream of the weights.  `sq_linear_ts_f16` (csrc/ts_linear.hip) runs them from fragment-major operand
