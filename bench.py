@@ -130,7 +130,8 @@ def kernel_rooflines(cfg, loop, device):
     # tall-skinny projections of the verify forward (q = tree size rows), rotating over the layers' weights so
     # that every launch streams its weights from HBM (32 x 33-180 MB >> the 256 MiB Infinity Cache)
     ts = getattr(tgt.model, "ts", None)
-    if ts is not None and n <= 128:
+    from sequoia_amd.Engine.ts_linear import MAX_ROWS as TS_MAX_ROWS
+    if ts is not None and n <= TS_MAX_ROWS:
         plan = ts.plan(n)
         for name in ("qkv", "o", "gate_up", "down"):
             if plan.get(name) is None:
@@ -157,6 +158,41 @@ def kernel_rooflines(cfg, loop, device):
 T_START = time.perf_counter()
 
 
+def source_sha(*names):
+    """sha256[:16] over kernel sources: a PMC record is only valid for the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(REPO, "sequoia_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_lookup(pmc_key, dom):
+    """HBM bytes per launch and MFMA utilisation of the dominant kernel from the newest profiles/r*_pmc.json (rocprofv3 PMC
+    passes, tools/pmc_r03.sh: FETCH_SIZE / WRITE_SIZE / SQ group in separate passes, gfx950 correction 2 FETCH + WRITE).
+    The record must carry the sha of the kernel source it was measured on and that sha must match the tree bench runs
+    from: a stale record gives traffic = null and says so.  -> (traffic, mfma_util, file, note)"""
+    import glob
+    src = "tree_attention.hip" if dom == "tree_attention_target" else "ts_linear.hip"
+    want = source_sha(src, "common.h")
+    notes = []
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+            rec = pm["kernels"][pmc_key]
+        except (OSError, KeyError, ValueError) as e:
+            notes.append(f"{os.path.basename(path)}: no record for {pmc_key} ({type(e).__name__})")
+            continue
+        have = (pm.get("source_sha") or {}).get(src)
+        if have != want:
+            notes.append(f"{os.path.basename(path)}: measured on {src} {have}, this tree has {want}")
+            continue
+        return rec["hbm_bytes_per_launch"], rec["mfma_util"], os.path.relpath(path, REPO), None
+    return None, None, None, "no valid PMC record for " + pmc_key + ": " + "; ".join(notes) + " -- re-run tools/pmc_r03.sh"
+
+
 def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=False):
     """The CPU path timed on this box's host cores: the same host loop with the reference's PyTorch op sequences
     restated for CPU tensors (oracle/ops_torch_cpu.py; verification on the numpy oracle) and PyTorch CPU GEMMs, fp16
@@ -170,15 +206,21 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
     from sequoia_amd import ops as ops_mod
     prev = ops_mod._OPS
     ops_mod.set_ops_for_testing(OracleOps() if numpy_ops else TorchCpuOps())     # numpy_ops: the checking oracle (slow)
-    # fp16 CPU GEMMs of <= 255 rows do not scale past a few dozen threads (128 threads: 13 s / step, 8 threads: 3.3 s)
+    # fp16 CPU GEMMs of <= 255 rows do not scale past a few dozen threads (128 threads: 13 s / step, 8 threads: 3.3 s on one
+    # box, the other way round on another): after the prefill step ONE steady step is timed at each of 8 / 16 / 32
+    # threads (SEQUOIA_CPU_THREADS=a,b,c overrides) and the fastest is the baseline -- the honest best of this host
     prev_threads = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(prev_threads, int(os.environ.get("SEQUOIA_CPU_THREADS", "32")))))
+    avail = os.cpu_count() or prev_threads
+    sweep = [int(x) for x in os.environ.get("SEQUOIA_CPU_THREADS", "8,16,32").split(",") if x.strip()]
+    sweep = sorted({max(1, min(t, avail)) for t in sweep}) or [prev_threads]
+    torch.set_num_threads(sweep[len(sweep) // 2])
     try:
         t0 = time.perf_counter()
         draft, target, gm = engines if engines is not None else build(cfg, "cpu", pair)
         build_s = time.perf_counter() - t0
         from sequoia_amd.Tree.GreedyTree import GreedyTree
         from sequoia_amd.Tree.SpecTree import SpecTree
+        from sequoia_amd.Tree._native_tree import COMMIT_ORDER
         M = cfg["M"]
         cls = SpecTree if cfg["mode"] == "stochastic" else GreedyTree
         p = torch.tensor(load_prompts()[0][:128], dtype=torch.long)
@@ -187,29 +229,82 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
                    draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
                    grow_map=gm.to_reference_dict(), attn_mask=None, sequence=None, new_tokens_buffer=None,
                    parents_buffer=None, position_ids=torch.zeros(M, dtype=torch.long), residual_graph=None,
-                   sampling_callables=None, sample_gather_indices=None, commit_order="reference")
-        cur, step_s, step_tok = len(p), [], []
-        for _ in range(max(2, n_steps)):
+                   sampling_callables=None, sample_gather_indices=None, commit_order=COMMIT_ORDER)
+        cur, step_s, step_tok, step_thr = len(p), [], [], []
+        n_total = max(2, n_steps, 1 + len(sweep))
+        for i in range(n_total):
+            thr = sweep[(i - 1) % len(sweep)] if i > 0 else sweep[len(sweep) // 2]
+            torch.set_num_threads(thr)
             t1 = time.perf_counter()
             tree.construct_grow_map()
             valid, _, _, term = tree.verify()
             step_s.append(time.perf_counter() - t1)
             step_tok.append(valid.shape[0] - cur)
+            step_thr.append(thr)
             cur = valid.shape[0]
             if term:
                 break
-        steady_s, steady_tok = sum(step_s[1:]), sum(step_tok[1:])
         n_steady = len(step_s) - 1
-        return dict(value=(steady_tok / steady_s) if n_steady else None, unit="tokens/s", cores=torch.get_num_threads(),
-                    kind="port",
+        by_thr = {}
+        for sec, thr in zip(step_s[1:], step_thr[1:]):
+            by_thr.setdefault(thr, []).append(sec)
+        mean_by_thr = {t: sum(v) / len(v) for t, v in by_thr.items()}
+        best_thr = min(mean_by_thr, key=mean_by_thr.get) if mean_by_thr else step_thr[0]
+        best_s = mean_by_thr.get(best_thr)
+        tok_per_step = (sum(step_tok[1:]) / n_steady) if n_steady else None
+        # the imported reference beside this port on the same weights / prompt / noise (oracle/ref_cpu_baseline.py, run in
+        # the build container: the reference checkout does not travel): seconds-per-step ratio, to scale `value`
+        ref_over_port = None
+        try:
+            with open(os.path.join(REPO, "profiles", "r02_cpu_reference_vs_port.json")) as f:
+                rp = json.load(f)
+            ref_over_port = rp["reference"]["steps_per_s"] / rp["port"]["steps_per_s"]
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            pass
+        return dict(value=(tok_per_step / best_s) if n_steady else None, unit="tokens/s", cores=best_thr,
+                    kind="port", commit_order=COMMIT_ORDER,
                     sample=f"{len(step_s)} speculation steps of prompt 0, config {cfg['draft']} -> {cfg['target']}, the "
-                           f"reference's torch op sequences on CPU fp16 tensors; step 0 (with the 255-token target prefill) {step_s[0]:.1f} s, "
-                           f"then {n_steady} steady steps in {steady_s:.1f} s (+{build_s:.0f} s weight init)",
-                    steps_per_s=(n_steady / steady_s) if n_steady else None, prefill_step_s=step_s[0],
-                    step_seconds=[round(x, 3) for x in step_s], step_tokens=step_tok, tokens=valid[:cur].tolist())
+                           f"reference's torch op sequences on CPU fp16 tensors; step 0 (with the 255-token target prefill) "
+                           f"{step_s[0]:.1f} s, then {n_steady} steady steps, one per thread count of {sweep}: "
+                           f"{ {t: round(v, 2) for t, v in mean_by_thr.items()} } s / step; value = mean tokens/step of the steady "
+                           f"steps / the fastest step time (+{build_s:.0f} s weight init)",
+                    steps_per_s=(1.0 / best_s) if n_steady else None, prefill_step_s=step_s[0],
+                    step_seconds=[round(x, 3) for x in step_s], step_threads=step_thr, step_tokens=step_tok,
+                    seconds_per_step_by_threads={str(t): round(v, 3) for t, v in mean_by_thr.items()},
+                    reference_over_port=ref_over_port, host_cores=avail, tokens=valid[:cur].tolist())
     finally:
         ops_mod.set_ops_for_testing(prev)
         torch.set_num_threads(prev_threads)
+
+
+def allreduce_timing(target, device, rows, reps=40):
+    """Tensor-parallel runs (collective: every rank calls it): one all-reduce of the verify forward's [rows, hidden] fp16
+    message, HIP events on the launch stream, for the engine's xGMI kernel (if it is active) and for RCCL."""
+    import torch.distributed as dist
+    inner = target.engine
+    hidden = inner.model.dims.hidden_size
+    x = torch.zeros((rows, hidden), dtype=torch.float16, device=device)
+    out = dict(kind=getattr(inner, "allreduce_kind", "rccl"), message_bytes=x.numel() * 2, per_verify=2 * inner.model.dims.num_hidden_layers)
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / reps], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+    if getattr(inner, "xgmi", None) is not None:
+        out["xgmi_us"] = timeit(lambda: inner.xgmi(x))
+        out["xgmi_status"] = inner.xgmi.status()
+    out["rccl_us"] = timeit(lambda: dist.all_reduce(x))
+    return out
 
 
 def spawn_ranks(n: int) -> int:
@@ -233,7 +328,7 @@ def tp_extra(n: int, args) -> dict:
     headline line with it.  Returns the child's JSON line (trimmed) or an error record."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--config", "E", "--steps", str(min(args.steps, 12)),
-           "--warmup", "2", "--no-cpu-baseline", "--no-autoregressive", "--no-tuned-growmap", "--no-tp-extra", "--sync-loop",
+           "--warmup", "2", "--no-cpu-baseline", "--no-autoregressive", "--no-tuned-growmap", "--no-tp-extra",
            "--backend", args.backend]
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
@@ -258,8 +353,12 @@ def tp_extra(n: int, args) -> dict:
     if out.returncode != 0 or not lines:
         return dict(error=f"rc {out.returncode}", stderr=out.stderr[-400:])
     d = json.loads(lines[-1])
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "mean_accepted_len", "rccl_ranks", "config")
-    return {k: d[k] for k in keep if k in d}
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "mean_accepted_len", "rccl_ranks", "config",
+            "roofline", "allreduce", "prefill_steps_in_timed_region")
+    out = {k: d[k] for k in keep if k in d}
+    if "config" in d:
+        out["step_loop"] = d["config"].get("step_loop")
+    return out
 
 
 def selftest(args, world, rank):
@@ -350,15 +449,24 @@ def main():
     loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs,
                 pipelined=not args.sync_loop and not args.no_graphs)
 
+    from sequoia_amd.Tree._native_tree import COMMIT_ORDER as commit_order
     loop.run_steps(args.warmup)
+    if tp_mode and world > 1:
+        from sequoia_amd.Engine.ts_linear import assert_same_plans_across_ranks
+        assert_same_plans_across_ranks(draft.engine.model, target.engine.model)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    p0 = loop.prefill_steps
     secs, new_tok, steps = loop.run_steps(args.steps)
     torch.cuda.synchronize()
+    prefill_steps = loop.prefill_steps - p0      # steps of the timed region that carried a prompt's target prefill
     rccl_ranks = 1
+    allreduce = None
     if world > 1:
         dist.barrier()
+        if tp_mode:
+            allreduce = allreduce_timing(target, device, gm.size)
         t = torch.tensor([secs], device=device); dist.all_reduce(t, op=dist.ReduceOp.MAX); secs = float(t)
         rccl_ranks = dist.get_world_size()
         if tp_mode:                    # all ranks produced the SAME tokens: count them once
@@ -387,22 +495,21 @@ def main():
                 pmc_key = "tree_attention_target7b"
             elif dom.startswith("linear_ts_"):
                 pmc_key = f"{dom[len('linear_ts_'):]}@{(gm.size + 15) // 16}:{d['plan'][0]}x{d['plan'][1]}"
+        pmc_file = None
         if pmc_key is not None:
-            try:
-                with open(os.path.join(REPO, "profiles", "r02_pmc.json")) as f:
-                    pm = json.load(f)["kernels"]
-                traffic, mfma_util = pm[pmc_key]["hbm_bytes_per_launch"], pm[pmc_key]["mfma_util"]
-            except (OSError, KeyError, ValueError) as e:
-                traffic_note = f"no PMC pass for {pmc_key} in profiles/r02_pmc.json ({type(e).__name__}): re-run tools/pmc_r02.sh"
+            traffic, mfma_util, pmc_file, traffic_note = pmc_lookup(pmc_key, dom)
+            if traffic_note:
                 print("bench.py: " + traffic_note, file=sys.stderr)
         roof = dict(bound="hbm", kernel=dom, achieved=d["bytes"] / d["seconds"] / 1e9, peak=peak_hbm, unit="GB/s",
                     frac=d["bytes"] / d["seconds"] / 1e9 / peak_hbm, traffic=traffic, mfma_util=mfma_util, pmc_key=pmc_key,
+                    pmc_file=pmc_file,
                     avg_launch_us=d["seconds"] * 1e6, algorithmic_bytes_per_launch=d["bytes"],
                     time_per_step_us=per_step[dom] * 1e6)
         if traffic_note:
             roof["traffic_note"] = traffic_note
         kernels = {k: dict(avg_us=v["seconds"] * 1e6, gbps=v["bytes"] / v["seconds"] / 1e9,
-                           per_step_us=per_step[k] * 1e6) for k, v in kr.items()}
+                           frac=v["bytes"] / v["seconds"] / 1e9 / peak_hbm, algorithmic_bytes=v["bytes"],
+                           launches_per_step=v["launches_per_step"], per_step_us=per_step[k] * 1e6) for k, v in kr.items()}
         tuned = None
         tuned_name = "MI355X-synthetic-68m-7b-stochastic"
         if not args.no_tuned_growmap and world == 1 and args.config == "B" and not args.growmap and args.pair == "calibrated":
@@ -450,12 +557,14 @@ def main():
                                          f"({gm.size}-node tree), T=0.6, top_p=1.0, M={cfg['M']}, 128-token c4_small "
                                          f"prompts, generate to 256",
                                 parallelism=(f"tp{world}" if tp_mode else ("replicas" if world > 1 else "single")), graphs=not args.no_graphs,
+                                commit_order=commit_order,
                                 step_loop="device-driven (one hipGraph per speculation step, results read one step late)"
                                 if loop.pipelined else "host-driven (one result read per step)",
                                 gemm="tree forwards (<= 144 rows): sq_linear_ts_f16 (fragment-major weight stream, plans "
                                      "ts_plans_gfx950.json); prompt prefill and lm_head at 128 rows: PyTorch GEMM ("
                                      + ("TunableOp-selected hipBLASLt / rocBLAS solutions" if gemm_tuned else "default algorithm") + ")"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs, rccl_ranks=rccl_ranks,
+                    prefill_steps_in_timed_region=prefill_steps, allreduce=allreduce,
                     roofline=roof, kernels=kernels, host_driven_loop=host_loop, mi355x_growmap=tuned,
                     autoregressive_baseline=autoreg,
                     cpu_baseline=cpu)
@@ -466,6 +575,8 @@ def main():
         if world > 1 and not tp_mode and not args.no_tp_extra:
             # the other ranks are exiting: their GPUs are free for the tensor-parallel child job
             del loop, draft, target
+            import gc
+            gc.collect()                     # step states (graphs, static buffers) hang off the target engine
             torch.cuda.empty_cache()
             time.sleep(3.0)
             spent = time.perf_counter() - T_START

@@ -43,9 +43,12 @@ extern "C" {
  * launch argument of a speculation step depends on the step, so construct_grow_map() + verify() + the next step's
  * preparation (Tree/SpecTree.py:245-281) replay as ONE hipGraph and the host reads the result record one step late. */
 #define SQ_STEP_GT        0  /* ground_truth_len the current step runs with                                     */
-#define SQ_STEP_NEXT_GT   1  /* written by sq_verify_*: gt of the next step (a + 1), or gt when terminal        */
+#define SQ_STEP_NEXT_GT   1  /* written by sq_verify_*: gt of the next step (a + 1); a when terminal -- a step in
+                                flight behind a terminal one then works beyond the finished text tokens[0, a)     */
 #define SQ_STEP_INDEX     2  /* step counter: indexes the bonus-uniform table and the result ring               */
-#define SQ_STEP_ACTIVE    3  /* cleared by sq_verify_* on a terminal step                                       */
+#define SQ_STEP_ACTIVE    3  /* cleared by sq_verify_* on a terminal step; while 0, sq_verify_* commits nothing
+                                (no token write, no accepted slots: the KV compactions move 0 rows) and reports
+                                a terminal record with reason SQ_REASON_SKIPPED                                  */
 #define SQ_STEP_INTS      8
 #define SQ_RESULT_RING    4  /* d_result_ring holds SQ_RESULT_RING records of SQ_RESULT_INTS ints, slot = index % ring */
 
@@ -55,7 +58,9 @@ extern "C" {
 #define SQ_RES_BONUS      2  /* bonus token id written to tokens[a], -1 when terminal       */
 #define SQ_RES_TERMINAL   3  /* 0 / 1                                                       */
 #define SQ_RES_REASON     4  /* 0 none, 1 EOS token accepted, 2 NaN residual, 3 no slot left for the bonus token
-                                (a >= token_capacity: the reference raises IndexError, Tree/SpecTree.py:222)  */
+                                (a >= token_capacity: the reference raises IndexError, Tree/SpecTree.py:222),
+                                4 skipped: the step ran behind a terminal one (device-driven loop)            */
+#define SQ_REASON_SKIPPED 4
 #define SQ_RES_GT         5  /* echo of the ground_truth_len the step ran with              */
 #define SQ_RES_LAST_NODE  6  /* tree-local id of the node the walk stopped at               */
 #define SQ_RES_SLOTS      8  /* [8, 8+min(N_TREE,56)): absolute slots of the accepted nodes  */
@@ -357,6 +362,29 @@ int sq_embed_rmsnorm_f16(const int64_t* d_ids, const void* embed, int vocab, con
  * slab: fp32 [splits][rows][hidden].                                                                  */
 int sq_add_rmsnorm_slabs_f16(const void* slab, int splits, const void* residual, const void* weight, void* sum_out,
                              void* out, int out_frag, int rows, int hidden, float eps, void* stream);
+
+/* ---- e: tensor-parallel all-reduce over peer-mapped buffers (xGMI) ------------------------------------------
+ * The 70B target replaces the reference's host offload (Engine/offload_engine.py:388-451) by tensor parallelism over
+ * the GPUs of one node: the row-parallel projections (o_proj, down_proj: Engine/Llama_modules.py:138,256,271 on a
+ * shard) leave a partial [q, hidden] fp16 product on every rank, 2 per layer.  sq_allreduce_sum_f16 sums them in
+ * place over buffers the ranks map into each other's address space (hipIpc), every rank talking to every peer at
+ * once (xGMI is point-to-point): reduce-scatter by direct peer stores, sum in fp32 in rank order (one rounding: all
+ * ranks get bit-identical rows), all-gather by direct peer stores; flags carry a device-resident epoch, so the launch
+ * replays from a hipGraph.  Stream-ordered, no host synchronisation, every spin bounded (sq_ar_status reports a
+ * timeout instead of hanging).  RCCL (torch.distributed) remains the fallback.
+ *   setup, once per rank: ws = sq_ar_alloc(sq_ar_workspace_bytes(world, max_elems)) (uncached device memory, zeroed),
+ *   sq_ar_ipc_export(ws, handle) -> exchange the 64-byte handles (any transport) -> sq_ar_ipc_open(peer handle);
+ *   call: ws[world] = every rank's workspace as mapped in the calling process (ws[rank] = own), identical n / blocks
+ *   on all ranks, n % 8 == 0, n <= max_elems; blocks <= 0 picks one block per 4 KB of a chunk (max 64).             */
+size_t sq_ar_workspace_bytes(int world, size_t max_elems);
+int sq_ar_alloc(void** ptr, size_t bytes);
+int sq_ar_free(void* ptr);
+int sq_ar_ipc_export(void* ptr, void* handle64);
+int sq_ar_ipc_open(const void* handle64, void** ptr);
+int sq_ar_ipc_close(void* ptr);
+int sq_ar_status(const void* own_ws, int* status);      /* 0 ok; bit 0 / 1: a phase-1 / phase-2 flag never arrived (host sync) */
+int sq_allreduce_sum_f16(void* data, size_t n, int rank, int world, void* const* ws, size_t max_elems, int blocks,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -77,13 +77,36 @@ def make_cfg(R, dims, vocab):
     return cfg
 
 
-def make_engine(R, outer, inner, model_cls, cfg, M, seed, logit_gain, dt=torch.float16):
+import contextlib
+
+
+@contextlib.contextmanager
+def _skip_param_init():
+    """Construct a model without running its random initialisers (seeded cases overwrite every parameter through
+    load_state_dict; a 7B-dims model would spend minutes drawing numbers that are thrown away)."""
+    saved = (torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters)
+    torch.nn.Linear.reset_parameters = lambda self: None
+    torch.nn.Embedding.reset_parameters = lambda self: None
+    try:
+        from transformers.modeling_utils import no_init_weights
+        cm = no_init_weights()
+    except Exception:
+        cm = contextlib.nullcontext()
+    try:
+        with cm:
+            yield
+    finally:
+        torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters = saved
+
+
+def make_engine(R, outer, inner, model_cls, cfg, M, seed, logit_gain, dt=torch.float16, skip_init=False):
     torch.manual_seed(seed)  # shim 4
     e = outer.__new__(outer)
     e.device = "cpu"; e.dtype = dt; e.max_length = M; e.callables = {}; e.mempool = None
     n = inner.__new__(inner)
     n.device = "cpu"; n.dtype = dt; n.max_length = M
-    model = model_cls(cfg)
+    with (_skip_param_init() if skip_init else contextlib.nullcontext()):
+        model = model_cls(cfg)
     with torch.no_grad():
         model.lm_head.weight.mul_(logit_gain)
     n.model = model.to(dt).eval(); n.model_config = cfg
@@ -107,7 +130,7 @@ def kv_checksum(engine):
 
 def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, prompt_len, max_steps, seed,
              logit_gain=24.0, share_weights=0.0, out_dir=None, seeded=False, share_vocab=0.0, compact=0,
-             branch_scale=1.0):
+             branch_scale=1.0, lead=None):
     """mode: 'stochastic' (SpecTree), 'greedy' (GreedyTree), 'specinfer' (SpecInferTree: draws with replacement)
     or 'greedys' (GreedySTree: greedy draft tree, target token sampled per node)."""
     RU = R["RU"]
@@ -115,8 +138,9 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
     n = g["size"]
     cfg_d = make_cfg(R, draft_dims, vocab)
     cfg_t = make_cfg(R, target_dims, vocab)
-    draft = make_engine(R, R["GIE"], R["IE"], R["MM"].LlamaForCausalLM_FI, cfg_d, M, 1, logit_gain)
-    target = make_engine(R, R["GIETG"], R["IETG"], R["MM"].LlamaForCausalLM_TG, cfg_t, M, 2, logit_gain)
+    big = seeded and target_dims[0] * target_dims[1] * target_dims[2] > (1 << 30)
+    draft = make_engine(R, R["GIE"], R["IE"], R["MM"].LlamaForCausalLM_FI, cfg_d, M, 1, logit_gain, skip_init=big)
+    target = make_engine(R, R["GIETG"], R["IETG"], R["MM"].LlamaForCausalLM_TG, cfg_t, M, 2, logit_gain, skip_init=big)
     if share_weights > 0.0:
         # correlated draft: draft weights = target weights + noise (same dims required)
         assert draft_dims == target_dims
@@ -131,7 +155,7 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
     if seeded:
         # weights regenerated from seeds on both sides (oracle/seeded_weights.py) instead of stored in the trace
         from oracle import seeded_weights as SW
-        sd_t = SW.seeded_state_dict(target_dims, vocab, 1000 + seed, logit_gain, branch_scale=branch_scale)
+        sd_t = SW.seeded_state_dict(target_dims, vocab, 1000 + seed, logit_gain, branch_scale=branch_scale, lead=lead)
         sd_d = SW.seeded_state_dict(draft_dims, vocab, 2000 + seed, logit_gain, branch_scale=branch_scale)
         if share_vocab > 0.0:
             SW.correlate(sd_d, sd_t, share_vocab, 3000 + seed)
@@ -139,7 +163,8 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
             missing, unexpected = eng.engine.model.load_state_dict(sd, strict=False)
             assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing), (missing, unexpected)
         seeded_meta = dict(draft_seed=2000 + seed, target_seed=1000 + seed, share_vocab=share_vocab,
-                           share_seed=3000 + seed, branch_scale=branch_scale, draft_checksum=str(SW.checksum(sd_d)),
+                           share_seed=3000 + seed, branch_scale=branch_scale, lead=list(lead) if lead else None,
+                           draft_checksum=str(SW.checksum(sd_d)),
                            target_checksum=str(SW.checksum(sd_t)))
     else:
         arrays.update(state_arrays(draft.engine.model, "draft"))
@@ -282,6 +307,20 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
                 arrays[f"{pre}/path_nodes"] = np.array(path_nodes, dtype=np.int64)
                 arrays[f"{pre}/path_target_rows"] = tl_n[path_nodes]
                 arrays[f"{pre}/path_draft_rows"] = dl_pre[path_nodes]
+            if compact and mode == "greedy":
+                # decision margins of the step (full rows are not stored): per internal node the k + 1 largest draft logits
+                # (k = its number of children: the top-k cut and the order inside it) and per node the gap between the two
+                # largest target logits (the verifier's argmax)
+                succ_ = g["Successors"]
+                kmax_ = max(len(c_) for c_ in succ_)
+                dtop = np.full((n, kmax_ + 1), np.nan, dtype=np.float32)
+                for t_ in range(n):
+                    k_ = len(succ_[t_])
+                    if k_:
+                        dtop[t_, :k_ + 1] = np.sort(dl_pre[t_].astype(np.float32))[::-1][:k_ + 1]
+                top2 = np.sort(tl_n.astype(np.float32), axis=1)[:, ::-1][:, :2]
+                arrays[f"{pre}/draft_top_vals"] = dtop
+                arrays[f"{pre}/target_top2_gap"] = (top2[:, 0] - top2[:, 1]).astype(np.float32)
             arrays[f"{pre}/valid_tokens"] = valid.numpy().copy()
             arrays[f"{pre}/accept_len"] = np.int64(a)
             arrays[f"{pre}/terminal"] = np.int64(int(terminal))
@@ -467,6 +506,16 @@ def main():
     run_case(R, "V32k_seq128", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), d68, t160, 32000,
              384, 0.6, "stochastic", 32, 5, 25, logit_gain=10.0, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.005,
              out_dir=out_dir)
+    # the headline dims (BASELINE.json configs[1] / [2]): 68m-dims draft -> Llama-2-7b-dims target (32 layers, 32 heads of
+    # D = 128, hidden 4096, inter 11008), V = 32000, M = 384, 128-token prompt like tests/testbed.py:57.  Weights seeded
+    # (13.5 GB of fp16 regenerated bit for bit on the GPU box); the target's leading 768 hidden dimensions carry most of
+    # the embedding / lm_head energy so that the 768-wide draft built from those slices gets accepted to a useful degree.
+    t7b = (4096, 11008, 32, 32, 32)
+    run_case(R, "B_7b", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), d68, t7b, 32000, 384, 0.6,
+             "stochastic", 128, 4, 41, logit_gain=3.0, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.0015,
+             lead=(768, 3.0), out_dir=out_dir)
+    run_case(R, "C_7b", gm("L40_growmaps/8x8-tree.pt"), d68, t7b, 32000, 384, 0.6, "greedy", 128, 4, 41, logit_gain=3.0,
+             seeded=True, share_vocab=0.05, compact=16, branch_scale=0.0015, lead=(768, 3.0), out_dir=out_dir)
     # the acceptance-rate probes of tests/test_accept.py (fp32 noise, p >= r q in fp32; top-k children / argmax)
     run_probe_case(R, "P_spectest", "spectest", tiny, 1024, 128, 0.6, 8, 16, 12, 31, noise=0.6, out_dir=out_dir)
     run_probe_case(R, "Q_greedytest", "greedytest", tiny, 1024, 128, 0.6, 8, 16, 12, 32, noise=0.6, out_dir=out_dir)

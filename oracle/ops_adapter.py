@@ -159,15 +159,32 @@ class OracleOps:
             return
         r = _np(result)
         r[7] = int(step[2])
-        step[1] = res["gt"] if res["terminal"] else res["accept_len"] + 1
+        nxt = res["accept_len"] + (0 if res["terminal"] else 1)
+        step[1] = nxt
         if res["terminal"]:
             step[3] = 0
         if result_ring is not None:
             slot = int(step[2]) % 4
             _np(result_ring)[slot * 64:(slot + 1) * 64] = r[:64]
 
+    def _skipped(self, step, result, result_ring):
+        """A step in flight behind a terminal one (SQ_STEP_ACTIVE == 0): the walker commits nothing (csrc/verify.hip)."""
+        if step is None or int(step[3]) != 0:
+            return False
+        gt = int(step[0])
+        self._fill(result, dict(accept_len=gt, n_tree=0, bonus=-1, terminal=1, reason=4, gt=gt, last_node=0, slots=[]))
+        r = _np(result)
+        r[7] = int(step[2])
+        step[1] = gt
+        if result_ring is not None:
+            slot = int(step[2]) % 4
+            _np(result_ring)[slot * 64:(slot + 1) * 64] = r[:64]
+        return True
+
     def verify_stochastic(self, target_logits, draft_logits, tokens, r, child_off, child_ids, n_tree, gt, temperature,
                           u24, workspace, result, step=None, bonus_table=None, result_ring=None):
+        if self._skipped(step, result, result_ring):
+            return result
         succ = _succ_from_csr(child_off, child_ids, n_tree)
         uni = int(u24) & 0xffffff
         if step is not None:
@@ -206,6 +223,8 @@ class OracleOps:
 
     def verify_greedy(self, target_logits, tokens, child_off, child_ids, n_tree, gt, workspace, result, step=None,
                       result_ring=None):
+        if self._skipped(step, result, result_ring):
+            return result
         succ = _succ_from_csr(child_off, child_ids, n_tree)
         if step is not None:
             gt = int(step[0])

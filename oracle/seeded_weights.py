@@ -48,8 +48,11 @@ def _shape(name: str, dims, vocab: int):
 
 
 def seeded_state_dict(dims, vocab: int, seed: int, logit_gain: float = 1.0, std: float = 0.02,
-                      branch_scale: float = 1.0) -> dict:
-    """dims = (hidden, inter, layers, heads, kv_heads).  fp16 tensors, HF parameter names."""
+                      branch_scale: float = 1.0, lead=None) -> dict:
+    """dims = (hidden, inter, layers, heads, kv_heads).  fp16 tensors, HF parameter names.
+    lead = (cols, factor): the first `cols` hidden dimensions of the embedding and of lm_head are scaled by `factor`, so
+    that a narrower draft built from those leading slices (`correlate`) predicts this model to a useful degree (the
+    headline-dims traces B_7b / C_7b: 768-wide draft, 4096-wide target)."""
     gen = torch.Generator()
     gen.manual_seed(int(seed))
     sd = {}
@@ -61,6 +64,12 @@ def seeded_state_dict(dims, vocab: int, seed: int, logit_gain: float = 1.0, std:
             sd[name] = torch.empty(shape, dtype=torch.float32).normal_(0.0, std, generator=gen).half()
     if logit_gain != 1.0:
         sd["lm_head.weight"] = (sd["lm_head.weight"].float() * logit_gain).half()
+    if lead is not None:
+        cols, factor = int(lead[0]), float(lead[1])
+        for k in ("model.embed_tokens.weight", "lm_head.weight"):
+            t = sd[k].float()
+            t[:, :cols] *= factor
+            sd[k] = t.half()
     if branch_scale != 1.0:            # damp the attention / MLP branches: the residual stream stays embedding-dominated
         for k in sd:
             if "o_proj" in k or "down_proj" in k:

@@ -23,6 +23,9 @@ import torch.distributed as dist
 from .Engine import GraphInferenceEngineTG, InferenceEngineTG
 
 FORCE_HOOKS = os.environ.get("SEQUOIA_TP_FORCE_HOOKS", "0") == "1"
+# all-reduce of the row-parallel projections: "xgmi" = the two-shot kernel over peer-mapped buffers (csrc/allreduce.hip,
+# Engine/xgmi_allreduce.py) with RCCL as the fallback when its setup or self-check fails; "rccl" = torch.distributed only
+ALLREDUCE = os.environ.get("SEQUOIA_TP_ALLREDUCE", "xgmi")
 
 
 class _TPInner(InferenceEngineTG):
@@ -31,6 +34,13 @@ class _TPInner(InferenceEngineTG):
         self.group = group
         self.world = world
         self.collectives = 0                 # all-reduce / all-gather calls issued (eager count; tests)
+        self.xgmi = None
+        if world > 1 and ALLREDUCE == "xgmi":
+            from .ts_linear import MAX_ROWS
+            from .xgmi_allreduce import XgmiAllReduce
+            self.xgmi = XgmiAllReduce.create(group, device, max_elems=MAX_ROWS * self.model.dims.hidden_size)
+            if self.xgmi is None and str(device).startswith("cuda") and os.environ.get("SEQUOIA_TP_REQUIRE_XGMI", "0") == "1":
+                raise RuntimeError("SEQUOIA_TP_REQUIRE_XGMI=1 but the xGMI all-reduce could not be set up (see stderr)")
         if world > 1 or FORCE_HOOKS:
             # (world 1 with SEQUOIA_TP_FORCE_HOOKS=1: a single-GPU box still runs every hook, RCCL call and capture)
             self.model.reduce_fn = self._all_reduce
@@ -38,9 +48,15 @@ class _TPInner(InferenceEngineTG):
 
     def _all_reduce(self, x):
         self.collectives += 1
+        if self.xgmi is not None and self.xgmi.fits(x):
+            return self.xgmi(x)              # one kernel: peer stores over xGMI, fp32 sum in rank order
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x
+
+    @property
+    def allreduce_kind(self):
+        return "xgmi two-shot (peer-mapped buffers)" if self.xgmi is not None else "rccl"
 
     def _gather_vocab(self, logits):
         """[q, V / world] per rank (rank r owns vocabulary rows [r V / world, (r + 1) V / world)) -> [q, V]."""

@@ -184,9 +184,18 @@ class TsLinearSet:
                     if rec is None or rec == "torch":
                         rec = self.default_plan(name, q_len)
                 elif capturing and (rec is None or not have_images):
+                    if DETERMINISTIC_PLANS:
+                        # replicated ranks must run identical arithmetic: a fallback that depends on this rank's warm-up
+                        # history is an error, not a choice
+                        raise RuntimeError(f"{name}@{q_len}: no launch plan / weight image before graph capture "
+                                           "(deterministic plans: run the forward eagerly once before capturing it)")
                     rec = "torch"          # no timing, no allocation, no repack inside a capture (the eager warm-ups
                     #                        of a graph runner come first and cache the real plan)
                 elif rec != "torch" and not have_images and not self._images_fit(name):
+                    if DETERMINISTIC_PLANS:
+                        raise RuntimeError(f"{name}: the fragment-major weight image does not fit this rank's free memory "
+                                           "(deterministic plans: a per-rank fallback would make the ranks' results differ; "
+                                           "use SEQUOIA_TS_EXCLUSIVE=1)")
                     rec = "torch"
                 elif rec is None and DETERMINISTIC_PLANS:
                     rec = "torch" if name == "lm_head" else self.default_plan(name, q_len)
@@ -262,6 +271,33 @@ class TsLinearSet:
             for li in range(n_layers):
                 self._frag.pop((name, li), None)
         return best
+
+
+def plan_signature(*models) -> str:
+    """Hash of every launch plan the given models have chosen so far (per q_len, per projection)."""
+    import hashlib
+    rows = []
+    for i, m in enumerate(models):
+        ts = getattr(m, "ts", None)
+        if ts is None:
+            rows.append((i, "no-ts"))
+            continue
+        for q in sorted(ts._plans):
+            rows.append((i, q, sorted((k, v) for k, v in ts._plans[q].items())))
+    return hashlib.sha256(repr(rows).encode()).hexdigest()[:16]
+
+
+def assert_same_plans_across_ranks(*models, group=None):
+    """Tensor-parallel jobs: the replicated draft / sampler / verifier rely on bit-identical arithmetic on every rank, so
+    every rank must have picked the same launch plans.  Call after the warm-up steps (collective; not inside a capture)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    mine = plan_signature(*models)
+    sigs = [None] * dist.get_world_size(group)
+    dist.all_gather_object(sigs, mine, group=group)
+    if len(set(sigs)) != 1:
+        raise RuntimeError(f"launch plans differ between tensor-parallel ranks: {sigs}")
 
 
 def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree, kv_cache):

@@ -1,0 +1,144 @@
+"""All-reduce of the tensor-parallel target's row-parallel projections over peer-mapped buffers (csrc/allreduce.hip).
+
+One process per GPU.  Every rank allocates one uncached workspace through the C ABI, exports it as a hipIpc handle,
+the 64-byte handles are exchanged once over torch.distributed (any backend: the transport of the SETUP, not of the data),
+and every rank maps its peers' workspaces.  After that an all-reduce is one kernel launch per rank -- no RCCL call, no
+host synchronisation, legal inside hipGraph capture -- in which each rank stores its 1/W slices straight into its
+peers' memory over its own xGMI links (include/sequoia_hip.h, section e).
+
+`XgmiAllReduce.create()` returns None (and says why) when the buffers cannot be set up or the self-check against
+`dist.all_reduce` fails; the caller then stays on RCCL.  Slot in the reference: Engine/offload_engine.py:388-451 (the
+host-offload engine this tensor-parallel engine replaces).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as dist
+
+from .. import native
+
+
+class XgmiAllReduce:
+    def __init__(self, lib, rank, world, ws_ptrs, own, opened, max_elems, device, group):
+        self.lib, self.rank, self.world = lib, rank, world
+        self._own, self._opened = own, opened
+        self.max_elems = max_elems
+        self.device, self.group = device, group
+        self._table = (C.c_void_p * world)(*ws_ptrs)
+        self.calls = 0
+
+    # ---- setup ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def create(group=None, device="cuda:0", max_elems=144 * 8192, self_check=True):
+        """max_elems: the largest tensor (fp16 elements) the job will reduce -- [144 rows, hidden]."""
+        if not (dist.is_available() and dist.is_initialized()) or not str(device).startswith("cuda"):
+            return None
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if world == 1 or world > 8:
+            return None
+        lib = native.load()
+        torch.cuda.set_device(device)
+        nbytes = int(lib.sq_ar_workspace_bytes(world, max_elems))
+        own = C.c_void_p()
+        ok = lib.sq_ar_alloc(C.byref(own), nbytes) == native.SQ_OK
+        handle = (C.c_ubyte * 64)()
+        if ok:
+            ok = lib.sq_ar_ipc_export(own, handle) == native.SQ_OK
+        # every rank learns whether every rank got its buffer: all or nothing
+        infos = [None] * world
+        dist.all_gather_object(infos, (bool(ok), bytes(handle), os.getpid()), group=group)
+        if not all(i[0] for i in infos):
+            if own.value:
+                lib.sq_ar_free(own)
+            return _refuse(rank, "workspace allocation / hipIpc export failed on rank(s) "
+                           + str([r for r, i in enumerate(infos) if not i[0]]))
+        ptrs, opened, failed = [], [], False
+        for r, (_, h, pid) in enumerate(infos):
+            if r == rank:
+                ptrs.append(own.value)
+                continue
+            p = C.c_void_p()
+            buf = (C.c_ubyte * 64).from_buffer_copy(h)
+            if lib.sq_ar_ipc_open(buf, C.byref(p)) != native.SQ_OK:
+                failed = True
+                ptrs.append(None)
+            else:
+                ptrs.append(p.value)
+                opened.append(p.value)
+        flags = [None] * world
+        dist.all_gather_object(flags, failed, group=group)
+        ar = XgmiAllReduce(lib, rank, world, ptrs if not failed else [own.value] * world, own, opened, max_elems, device, group)
+        if any(flags):
+            ar.close()
+            return _refuse(rank, "hipIpcOpenMemHandle failed on rank(s) " + str([r for r, f in enumerate(flags) if f]))
+        if self_check and not ar._self_check():
+            ar.close()
+            return None
+        return ar
+
+    def _self_check(self) -> bool:
+        """A few reductions of rank-dependent data against dist.all_reduce (which also keeps the ranks in step); all
+        ranks must agree that all ranks passed."""
+        ok = True
+        gen = torch.Generator(device="cpu")
+        for i, n in enumerate((8, 4096, 129 * 1024, min(self.max_elems, 129 * 8192))):
+            n = (min(n, self.max_elems) // 8) * 8
+            gen.manual_seed(1000 * i + self.rank)
+            x = (torch.randn(n, generator=gen) * 2).to(torch.float16).to(self.device)
+            want = x.float()
+            dist.all_reduce(want, group=self.group)
+            got = self(x.clone())
+            torch.cuda.synchronize(self.device)
+            if self.status() != 0 or not torch.allclose(got.float(), want, rtol=0, atol=2e-2 * self.world):
+                ok = False
+                break
+            # bit-identical on every rank (each element is reduced by exactly one rank)
+            same = got.clone().view(torch.int16).to(torch.int32)
+            lo, hi = same.clone(), same.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo, hi):
+                ok = False
+                break
+        verdicts = [None] * self.world
+        dist.all_gather_object(verdicts, ok, group=self.group)
+        if not all(verdicts):
+            _refuse(self.rank, f"self-check against dist.all_reduce failed on rank(s) {[r for r, v in enumerate(verdicts) if not v]}"
+                               f" (status {self.status()})")
+        return all(verdicts)
+
+    # ---- the call ---------------------------------------------------------------------------------------------
+    def __call__(self, x: torch.Tensor, blocks: int = 0) -> torch.Tensor:
+        """In-place sum over the ranks of a contiguous fp16 tensor (numel % 8 == 0, numel <= max_elems)."""
+        if x.dtype != torch.float16 or not x.is_contiguous() or x.device.type != "cuda":
+            raise TypeError("xgmi all-reduce: contiguous fp16 tensor on the device")
+        native.check(self.lib.sq_allreduce_sum_f16(x.data_ptr(), x.numel(), self.rank, self.world, self._table, self.max_elems,
+                                                   int(blocks), torch.cuda.current_stream().cuda_stream), "sq_allreduce_sum_f16")
+        self.calls += 1
+        return x
+
+    def fits(self, x: torch.Tensor) -> bool:
+        return x.dtype == torch.float16 and x.is_contiguous() and x.numel() % 8 == 0 and 0 < x.numel() <= self.max_elems
+
+    def status(self) -> int:
+        st = C.c_int(0)
+        self.lib.sq_ar_status(self._own, C.byref(st))
+        return int(st.value)
+
+    def close(self):
+        for p in self._opened:
+            self.lib.sq_ar_ipc_close(C.c_void_p(p))
+        self._opened = []
+        if self._own is not None and self._own.value:
+            self.lib.sq_ar_free(self._own)
+            self._own = None
+
+
+def _refuse(rank, why):
+    if rank == 0:
+        import sys
+        print(f"sequoia_amd: xGMI all-reduce disabled ({why}); staying on RCCL", file=sys.stderr)
+    return None

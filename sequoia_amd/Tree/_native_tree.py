@@ -17,8 +17,8 @@ import time
 import torch
 
 from ..Engine.Llama_modules import TreeContext
-from ..native import (SQ_VERIFY_GATHER_FIRST, SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_TERMINAL, SQ_RESULT_INTS,
-                      SQ_RESULT_RING)
+from ..native import (SQ_REASON_SKIPPED, SQ_VERIFY_GATHER_FIRST, SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_TERMINAL,
+                      SQ_RESULT_INTS, SQ_RESULT_RING)
 from ..ops import get_ops
 from .Tree import Tree, growmap_on_device
 
@@ -28,14 +28,17 @@ def _sync(device):
         torch.cuda.synchronize()
 
 
-# SpecTree / SpecInferTree commit order.  "lossless" (default): the accepted tokens are gathered first, then the bonus
-# token is stored, so the committed text is exactly the accepted path and agrees with the compacted KV rows (the
-# algorithm as published; an upstream bug fix).  "reference": bonus token stored BEFORE the gather, like
-# Tree/SpecTree.py:222-224 -- an accepted node sitting at slot gt + n_accepted (e.g. the root's second child accepted
-# alone) is then committed with the bonus token's id while its KV rows belong to the original token.  Only the
-# trace-parity tests (which replay runs of the reference itself) ask for it: SEQUOIA_COMMIT_ORDER=reference or
-# `tree.commit_order = "reference"`.
-COMMIT_ORDER = os.environ.get("SEQUOIA_COMMIT_ORDER", "lossless")
+# SpecTree / SpecInferTree commit order.  "reference" (default: this package is a drop-in, its token stream is the
+# reference's): the bonus token is stored BEFORE the accepted tokens are gathered, like Tree/SpecTree.py:222-224 -- an
+# accepted node sitting at slot gt + n_accepted (e.g. the root's second child accepted alone) is then committed with the
+# bonus token's id while its KV rows belong to the original token (an upstream quirk, a few percent of the steps on the
+# 128-node growmap; tests/test_properties_gpu.py::test_reference_commit_order_quirk).  "lossless": gather first, then
+# store the bonus token, so the committed text is exactly the accepted path (the algorithm as published):
+# SEQUOIA_COMMIT_ORDER=lossless, or `commit_order="lossless"` per tree.  bench.py prints the order it ran with
+# (`config.commit_order`) and times its CPU baseline with the same one.
+COMMIT_ORDER = os.environ.get("SEQUOIA_COMMIT_ORDER", "reference")
+if COMMIT_ORDER not in ("reference", "lossless"):
+    raise ValueError(f"SEQUOIA_COMMIT_ORDER must be 'reference' or 'lossless', got {COMMIT_ORDER!r}")
 # Device-driven step (Tree/step_graph.py): "1" = every tree adopts the static step buffers and can run pipelined steps
 # (enqueue_step / collect_step); the synchronous reference API (construct_grow_map / verify) works either way.
 STEP_GRAPH = os.environ.get("SEQUOIA_STEP_GRAPH", "0") == "1"
@@ -92,7 +95,10 @@ class NativeTree(Tree):
             # same CPU-generator draws, in the same order, as the reference (Tree/SpecTree.py:60,84)
             self.r = self._draw_r(len(position_ids)).to(self.device)
             if self.state is not None:
-                self.state.r[:len(self.r)].copy_(self.r)
+                # (the draw above has the reference's length, len(position_ids), for RNG-order parity; slots past
+                # max_length never exist, so the static buffer keeps the first M values)
+                m = min(len(self.r), self.state.r.numel())
+                self.state.r[:m].copy_(self.r[:m])
                 self.r = self.state.r
         self.depth = self.gdev["depth"][1:]
         self.position_ids[gt: gt + n - 1] = self.depth + (gt - 1)
@@ -340,6 +346,11 @@ class NativeTree(Tree):
         rec = rec.copy()
         a, n_acc, bonus, terminal = int(rec[SQ_RES_ACCEPT_LEN]), int(rec[SQ_RES_N_TREE]), int(rec[2]), bool(rec[SQ_RES_TERMINAL])
         assert int(rec[7]) == idx, f"result ring slot {idx % SQ_RESULT_RING} holds step {int(rec[7])}, expected {idx}"
+        if p["dead"]:
+            # a step that was in flight behind the terminal one: the device skipped its commit (SQ_STEP_ACTIVE == 0,
+            # csrc/verify.hip) -- the text, the caches and the host mirrors stay as the terminal step left them
+            assert terminal and n_acc == 0 and int(rec[4]) == SQ_REASON_SKIPPED, f"step {idx} ran behind a terminal step but committed"
+            return self.ground_truth_len, 0, -1, True
         self.last_result = rec
         self.step_idx = idx + 1
         if terminal:

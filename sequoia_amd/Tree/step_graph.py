@@ -19,7 +19,6 @@ from ..native import (SQ_RES_ACCEPT_LEN, SQ_RES_BONUS, SQ_RES_N_TREE, SQ_RES_TER
 from ..ops import get_ops
 from .Tree import _content_key
 
-_STATES: dict = {}
 N_BONUS = 1024
 
 
@@ -41,13 +40,22 @@ class StepState:
 
     @staticmethod
     def get(tree) -> "StepState":
-        key = (id(tree.draft_model_engine), id(tree.target_model_engine), _content_key(tree.grow_map), type(tree).__name__,
+        # The states live ON the target engine object (not in a module-level table): a StepState references both engines
+        # (weights, KV caches), a captured graph with its private pool and [n, V] buffers -- it has to die with the
+        # engines it serves (`del draft, target` frees everything; StepState.release(target) drops the states early).
+        key = (id(tree.draft_model_engine), _content_key(tree.grow_map), type(tree).__name__,
                float(tree.temperature), float(tree.top_p), int(tree.max_length), int(tree.vocab_size), str(tree.device),
                tree.commit_order)
-        st = _STATES.get(key)
-        if st is None:
-            st = _STATES[key] = StepState(tree)
+        table = tree.target_model_engine.__dict__.setdefault("_step_states", {})
+        st = table.get(key)
+        if st is None or st.draft is not tree.draft_model_engine:
+            st = table[key] = StepState(tree)
         return st
+
+    @staticmethod
+    def release(target_engine):
+        """Drop every step state (graphs, static buffers) captured for this target engine."""
+        target_engine.__dict__.pop("_step_states", None)
 
     def __init__(self, tree):
         dev, n, V, M = tree.device, tree.tree_size, tree.vocab_size, tree.max_length

@@ -1,0 +1,225 @@
+// e: tensor-parallel all-reduce(sum) of the row-parallel projections' partial outputs over peer-mapped buffers -- the
+// reference's counterpart is the host-offload path this build replaces (Engine/offload_engine.py:388-451); the exchange
+// itself has no reference line (2 all-reduces per layer of [q, hidden] fp16, 2.1 MB for the 129-node tree).
+//
+// xGMI is point-to-point (7 links per GPU): a ring all-reduce crosses 2 (W - 1) hops in sequence and each hop pays a
+// flag round trip, so a 2 MB message is latency-bound on it.  Here every rank talks to every peer at once, two phases
+// ("two-shot"), each over all links in parallel:
+//   phase 1 (reduce-scatter): rank r stores chunk p of its input straight into peer p's receive area (slot r);
+//   phase 2 (all-gather):     rank p sums the W copies of chunk p -- fp32, in RANK ORDER 0..W-1, one rounding to fp16 --
+//                             and stores the result into every peer's result area; each element is reduced by exactly
+//                             one rank, so all ranks end up with bit-identical rows (the replicated draft / sampler /
+//                             verifier of the tensor-parallel loop rely on that);
+//   phase 3: every rank copies the W - 1 foreign chunks from its result area into the caller's tensor.
+// A chunk is cut into `blocks` sub-ranges; block b of every rank owns sub-range b in all three phases, so the only
+// synchronisation is per (peer, block): one 4-byte flag per phase, carrying the call's epoch (monotonic, kept in device
+// memory: the launch has no step-dependent argument and replays from a hipGraph).  The workspace is allocated uncached
+// (MTYPE UC: remote stores and local reads bypass the XCD L2s) and exported through hipIpc; every spin is bounded and
+// reports through a status word instead of hanging the GPU.
+#include "common.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define AR_MAX_WORLD 8
+#define AR_MAX_BLOCKS 64
+#define AR_THREADS 512
+#define AR_FLAG_STRIDE 16                 // uint32 per flag slot: one 64-byte line each
+#define AR_SPIN_LIMIT (1u << 22)          // x (poll + s_sleep) ~ a few seconds; SEQUOIA_AR_SPIN_LIMIT overrides (tests)
+
+// workspace layout (bytes): [header 4 KB: status, per-block epochs] [flags1][flags2][area A: W slots][area B: n elements]
+struct ArLayout {
+    size_t flags1, flags2, area_a, area_b, total, chunk_cap;
+};
+__host__ __device__ static inline ArLayout ar_layout(int world, size_t max_elems) {
+    ArLayout L;
+    const size_t flag_bytes = (size_t)AR_MAX_WORLD * AR_MAX_BLOCKS * AR_FLAG_STRIDE * 4;
+    const size_t chunk = ((max_elems + world - 1) / world + 7) / 8 * 8;          // elements per chunk, 16-byte multiple
+    L.chunk_cap = chunk;
+    L.flags1 = 4096;
+    L.flags2 = L.flags1 + flag_bytes;
+    L.area_a = L.flags2 + flag_bytes;
+    L.area_b = L.area_a + (size_t)world * chunk * 2;
+    L.total = L.area_b + (size_t)world * chunk * 2;
+    return L;
+}
+
+struct ArParams {
+    half_t* data;                    // [n] in / out (local)
+    char* ws[AR_MAX_WORLD];          // workspace of every rank as mapped in THIS process (ws[rank] = own)
+    size_t n, max_elems;
+    int rank, world, blocks;
+    uint32_t spin_limit;
+};
+
+__device__ __forceinline__ void ar_flag_store(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool ar_flag_wait(const uint32_t* p, uint32_t want, uint32_t spin_limit) {
+    for (uint32_t it = 0; it < spin_limit; ++it) {
+        // relaxed polls, ONE acquire after the hit (acquire loads in the loop cost 2-3x per hop); epochs only grow: a
+        // peer that is already one call ahead has, by construction, finished this one
+        if ((int32_t)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) >= 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const ArParams P) {
+    const int b = blockIdx.x, tid = threadIdx.x, W = P.world, R = P.rank;
+    const ArLayout L = ar_layout(W, P.max_elems);
+    char* mine = P.ws[R];
+    uint32_t* status = (uint32_t*)mine;                       // [0] error bits
+    uint32_t* epochs = (uint32_t*)(mine + 256);               // [blocks]
+    __shared__ uint32_t s_epoch;
+    if (tid == 0) s_epoch = epochs[b] + 1;
+    __syncthreads();
+    const uint32_t epoch = s_epoch;
+
+    const size_t chunk = ((P.n + W - 1) / W + 7) / 8 * 8;     // elements (multiple of 8); the last chunk may be short
+    const size_t vec_per_chunk = chunk / 8;
+    const size_t v0 = vec_per_chunk * b / P.blocks, v1 = vec_per_chunk * (b + 1) / P.blocks;   // this block's 16-byte vectors
+    const size_t n_vec = P.n / 8;                             // n is a multiple of 8 (checked by the host entry)
+
+    // ---- phase 1: my copy of chunk p -> peer p's area A, slot R ---------------------------------------------------
+    for (int d = 1; d < W; ++d) {
+        const int p = (R + d) % W;                            // staggered: at any moment every link carries one stream
+        half_t* dst = (half_t*)(P.ws[p] + L.area_a) + (size_t)R * L.chunk_cap;
+        for (size_t v = v0 + tid; v < v1; v += AR_THREADS) {
+            const size_t g = (size_t)p * vec_per_chunk + v;
+            if (g < n_vec) *(u32x4*)(dst + v * 8) = *(const u32x4*)(P.data + g * 8);
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < W && tid != R)
+        ar_flag_store((uint32_t*)(P.ws[tid] + L.flags1) + ((size_t)R * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch);
+
+    // ---- phase 2: reduce my chunk (rank order, fp32), publish it to every peer's area B ----------------------------------
+    if (tid < W && tid != R) {
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags1) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit)) {
+            atomicOr(status, 1u);
+        }
+    }
+    __syncthreads();
+    {
+        const half_t* a = (const half_t*)(mine + L.area_a);
+        for (size_t v = v0 + tid; v < v1; v += AR_THREADS) {
+            const size_t g = (size_t)R * vec_per_chunk + v;
+            if (g >= n_vec) continue;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            for (int p = 0; p < W; ++p) {
+                const half8 x = p == R ? *(const half8*)(P.data + g * 8)
+                                       : __builtin_nontemporal_load((const half8*)(a + (size_t)p * L.chunk_cap + v * 8));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)x[j];
+            }
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+            *(half8*)(P.data + g * 8) = o;
+            for (int d = 1; d < W; ++d) {
+                const int p = (R + d) % W;
+                *(half8*)((half_t*)(P.ws[p] + L.area_b) + (size_t)R * L.chunk_cap + v * 8) = o;
+            }
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < W && tid != R)
+        ar_flag_store((uint32_t*)(P.ws[tid] + L.flags2) + ((size_t)R * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch);
+
+    // ---- phase 3: the other ranks' reduced chunks -> the caller's tensor ----------------------------------------------------
+    if (tid < W && tid != R) {
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit)) {
+            atomicOr(status, 2u);
+        }
+    }
+    __syncthreads();
+    {
+        const half_t* bsrc = (const half_t*)(mine + L.area_b);
+        for (int d = 1; d < W; ++d) {
+            const int p = (R + d) % W;
+            for (size_t v = v0 + tid; v < v1; v += AR_THREADS) {
+                const size_t g = (size_t)p * vec_per_chunk + v;
+                if (g < n_vec) *(half8*)(P.data + g * 8) = __builtin_nontemporal_load((const half8*)(bsrc + (size_t)p * L.chunk_cap + v * 8));
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) epochs[b] = epoch;           // the next call (or graph replay) of this block uses epoch + 1
+}
+
+extern "C" size_t sq_ar_workspace_bytes(int world, size_t max_elems) {
+    if (world < 1 || world > AR_MAX_WORLD || max_elems == 0) return 0;
+    return ar_layout(world, max_elems).total;
+}
+
+extern "C" int sq_ar_alloc(void** ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return SQ_EINVAL;
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return SQ_EUNSUPPORTED; }
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return SQ_ELAUNCH; }
+    *ptr = p;
+    return SQ_OK;
+}
+
+extern "C" int sq_ar_free(void* ptr) {
+    return (ptr && hipFree(ptr) == hipSuccess) ? SQ_OK : SQ_EINVAL;
+}
+
+extern "C" int sq_ar_ipc_export(void* ptr, void* handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+    if (!ptr || !handle64) return SQ_EINVAL;
+    if (hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, ptr) != hipSuccess) { (void)hipGetLastError(); return SQ_EUNSUPPORTED; }
+    return SQ_OK;
+}
+
+extern "C" int sq_ar_ipc_open(const void* handle64, void** ptr) {
+    if (!handle64 || !ptr) return SQ_EINVAL;
+    hipIpcMemHandle_t h;
+    __builtin_memcpy(&h, handle64, sizeof(h));
+    if (hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return SQ_EUNSUPPORTED; }
+    return SQ_OK;
+}
+
+extern "C" int sq_ar_ipc_close(void* ptr) {
+    return (ptr && hipIpcCloseMemHandle(ptr) == hipSuccess) ? SQ_OK : SQ_EINVAL;
+}
+
+extern "C" int sq_ar_status(const void* own_ws, int* status) {
+    if (!own_ws || !status) return SQ_EINVAL;
+    return hipMemcpy(status, own_ws, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess ? SQ_OK : SQ_ELAUNCH;
+}
+
+extern "C" int sq_allreduce_sum_f16(void* data, size_t n, int rank, int world, void* const* ws, size_t max_elems, int blocks,
+                                    void* stream) {
+    if (!data || !ws || world < 1 || world > AR_MAX_WORLD || rank < 0 || rank >= world || n == 0) return SQ_EINVAL;
+    if (n > max_elems || (n & 7) || ((uintptr_t)data & 15)) return SQ_EUNSUPPORTED;
+    if (world == 1) return SQ_OK;
+    ArParams P;
+    P.data = (half_t*)data; P.n = n; P.max_elems = max_elems; P.rank = rank; P.world = world;
+    for (int i = 0; i < AR_MAX_WORLD; ++i) P.ws[i] = i < world ? (char*)ws[i] : nullptr;
+    for (int i = 0; i < world; ++i)
+        if (!P.ws[i]) return SQ_EINVAL;
+    if (blocks <= 0) {
+        // one block per 4 KB of a chunk keeps a block's three phases short (the flags are per block) without starving the
+        // links: 2.1 MB over 8 ranks = 264 KB chunks -> 64 blocks; tiny messages take one
+        const size_t chunk_bytes = (n + world - 1) / world * 2;
+        blocks = (int)((chunk_bytes + 4095) / 4096);
+    }
+    P.blocks = blocks < 1 ? 1 : (blocks > AR_MAX_BLOCKS ? AR_MAX_BLOCKS : blocks);
+    static uint32_t spin_limit = 0;
+    if (!spin_limit) {
+        const char* e = getenv("SEQUOIA_AR_SPIN_LIMIT");
+        const long v = e ? atol(e) : 0;
+        spin_limit = v > 0 ? (uint32_t)v : AR_SPIN_LIMIT;
+    }
+    P.spin_limit = spin_limit;
+    hipLaunchKernelGGL(allreduce_two_shot_kernel, dim3(P.blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, P);
+    return sq_check_launch();
+}

@@ -265,8 +265,10 @@ static int ts_dispatch(const TsParams& P, int silu, int nt, hipStream_t st) {
     else if (nt <= 3) ts_go<MT, 3, false>(P, st);
     else if (nt <= 4) ts_go<MT, 4, false>(P, st);
     else if (nt <= 6) ts_go<MT, 6, false>(P, st);
-    else if (nt <= 8) ts_go<MT, 8, false>(P, st);
-    else return SQ_EUNSUPPORTED;
+    else if constexpr (MT <= 8) {                       // 9 x 8 accumulator tiles + a ring of 2 do not fit 512 registers
+        if (nt <= 8) ts_go<MT, 8, false>(P, st);        // (52 spilled VGPRs): 129-144 rows take <= 6 column tiles
+        else return SQ_EUNSUPPORTED;
+    } else return SQ_EUNSUPPORTED;
     return SQ_OK;
 }
 

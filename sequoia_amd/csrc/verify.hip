@@ -394,6 +394,28 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, int to
     const VerifyWs ws = ws_layout(ws_raw, n_tree);
     if (threadIdx.x != 0) return;
     const int gt = step_gt(d_step, gt_arg);
+    if (d_step && d_step[SQ_STEP_ACTIVE] == 0) {
+        // A step that was enqueued behind a terminal one (device-driven loop, steps in flight): it commits nothing.
+        // tokens[0, gt) -- the finished text -- and the compacted KV rows stay as the terminal step left them (its gt
+        // is the terminal step's accept length, so everything this step's samplers and forwards wrote lies beyond the
+        // text); the record says "skipped" and the step block does not move.
+        for (int i = 0; i < SQ_RESULT_INTS; ++i) result[i] = 0;
+        result[SQ_RES_ACCEPT_LEN] = gt;
+        result[SQ_RES_BONUS] = -1;
+        result[SQ_RES_TERMINAL] = 1;
+        result[SQ_RES_REASON] = SQ_REASON_SKIPPED;
+        result[SQ_RES_GT] = gt;
+        result[7] = d_step[SQ_STEP_INDEX];
+        d_step[SQ_STEP_NEXT_GT] = gt;
+        if (d_ring) {
+            int32_t* slot = d_ring + ((uint32_t)d_step[SQ_STEP_INDEX] % SQ_RESULT_RING) * SQ_RESULT_INTS;
+            for (int i = 0; i < SQ_RESULT_INTS; ++i)
+                if (i != 7) slot[i] = result[i];
+            __threadfence_system();
+            __hip_atomic_store(slot + 7, result[7], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     const int greedy = (mode & 3) == 1;
     const int gather_first = greedy || (mode & 4);
     mode &= 3;
@@ -462,7 +484,11 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, int to
     result[7] = d_step ? d_step[SQ_STEP_INDEX] : 0;
     if (d_step) {
         // device-driven step: the next step starts at new_gt = a + 1 (the bonus token is committed at slot a)
-        d_step[SQ_STEP_NEXT_GT] = terminal ? gt : a + 1;
+        // A terminal step leaves gt = a: steps already in flight behind it then work beyond the finished text
+        // (tokens[0, a) and the KV rows compacted to [gt, a) are not touched again) and skip their commit (above).
+        int next = terminal ? a : a + 1;
+        if (terminal && token_capacity > 0 && next + n_tree - 1 > token_capacity) next = gt;     // keep a follower in bounds
+        d_step[SQ_STEP_NEXT_GT] = next;
         if (terminal) d_step[SQ_STEP_ACTIVE] = 0;
         if (d_ring) {
             // copy of the header for the host, one slot per step.  The ring may live in pinned host memory (the host then

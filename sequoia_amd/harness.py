@@ -32,6 +32,17 @@ MODELS = {
 }
 
 
+def tp_capturable() -> bool:
+    """Can the tensor-parallel forward be captured into a hipGraph?  Yes with RCCL (backend "nccl") or without a process
+    group; not with gloo (its collectives run through the host).  SEQUOIA_TP_GRAPHS=0 forces eager forwards."""
+    if os.environ.get("SEQUOIA_TP_GRAPHS", "1") == "0":
+        return False
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_backend() == "nccl"
+
+
 def load_prompts():
     with open(os.path.join(_PKG, "growmaps", "c4_small_prompts.json")) as f:
         return json.load(f)["prompts"]
@@ -85,13 +96,18 @@ class Loop:
         if use_graphs:
             lens = sorted({lv.total for lv in g.levels} | {1})
             draft.initialize_cuda_graph(lens, tree_bitmask=gdev["bitmask"], n_tree=g.size)
-            # (tensor-parallel target: the verify forward is captured with its RCCL all-reduces only on request)
-            if hasattr(target, "initialize_cuda_graph") and (not cfg.get("tp") or os.environ.get("SEQUOIA_TP_GRAPHS", "0") == "1"):
+            # (tensor-parallel target: the verify forward is captured WITH its collectives -- the xGMI all-reduce kernel
+            # and RCCL calls are stream-ordered and legal inside a capture; a gloo group is not: eager then)
+            if hasattr(target, "initialize_cuda_graph") and (not cfg.get("tp") or tp_capturable()):
                 target.initialize_cuda_graph([g.size], tree_bitmask=gdev["bitmask"], n_tree=g.size)
         self.pi = 0
         self.tree = None
         self.cur_len = 0
-        self.pipelined = bool(pipelined) and str(device).startswith("cuda") and not cfg.get("tp")
+        self.prefill_steps = 0       # steps that carried a prompt's target prefill (the first verify of every prompt)
+        # device-driven steps under tensor parallelism too: the step block, the result ring and the decisions are per
+        # rank and identical on every rank (replicated draft / sampler / verifier, same noise), so every rank replays
+        # the same whole-step graph -- collectives included -- without any broadcast
+        self.pipelined = bool(pipelined) and str(device).startswith("cuda") and (not cfg.get("tp") or tp_capturable())
 
     def _new_prompt(self):
         self.draft.clear_kv(); self.target.clear_kv()
@@ -133,6 +149,8 @@ class Loop:
                     length = a if terminate else a + 1
                     last = bonus
                 else:
+                    if tree.target_kv_len == 0:
+                        self.prefill_steps += 1
                     tree.construct_grow_map()
                     valid, a, _, terminate = tree.verify()
                     length = valid.shape[0]

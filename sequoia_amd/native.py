@@ -19,6 +19,7 @@ SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_BONUS, SQ_RES_TERMINAL = 0, 1, 2, 3
 SQ_RES_REASON, SQ_RES_GT, SQ_RES_LAST_NODE, SQ_RES_SLOTS = 4, 5, 6, 8
 SQ_STEP_GT, SQ_STEP_NEXT_GT, SQ_STEP_INDEX, SQ_STEP_ACTIVE, SQ_STEP_INTS = 0, 1, 2, 3, 8
 SQ_RESULT_RING = 4
+SQ_REASON_SKIPPED = 4
 SQ_ATT_OUT_FRAG = 0x100
 SQ_VERIFY_GATHER_FIRST = 0x80000000
 
@@ -67,6 +68,14 @@ PROTOTYPES = {
     "sq_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_add_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_silu_mul_frag_f16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sq_ar_workspace_bytes": (C.c_size_t, [_i, C.c_size_t]),
+    "sq_ar_alloc": (_i, [C.POINTER(_vp), C.c_size_t]),
+    "sq_ar_free": (_i, [_vp]),
+    "sq_ar_ipc_export": (_i, [_vp, _vp]),
+    "sq_ar_ipc_open": (_i, [_vp, C.POINTER(_vp)]),
+    "sq_ar_ipc_close": (_i, [_vp]),
+    "sq_ar_status": (_i, [_vp, C.POINTER(_i)]),
+    "sq_allreduce_sum_f16": (_i, [_vp, C.c_size_t, _i, _i, C.POINTER(_vp), C.c_size_t, _i, _vp]),
 }
 
 _lib = None

@@ -179,9 +179,14 @@ class HipOps:
             if torch.cuda.is_current_stream_capturing():
                 raise native.SequoiaNativeError("sampler workspace must be sized before graph capture (run the step eagerly once)")
             want = max(need, int(self.lib.sq_sample_workspace_bytes(native.SQ_MAX_TREE, int(vocab), 32)))
+            old = ws
             ws = torch.empty(want, dtype=torch.uint8, device=device)
             if not hasattr(self, "_samp_ws"):
-                self._samp_ws = {}
+                self._samp_ws, self._samp_ws_retired = {}, []
+            if old is not None:
+                # a captured graph (whole-step graph, sampler callables) may have the old buffer's address baked into
+                # its launches: it must stay allocated for the life of the process, not return to the caching allocator
+                self._samp_ws_retired.append(old)
             self._samp_ws[key] = ws
         return ws
 

@@ -37,6 +37,10 @@ def load_trace(name):
 TRACE_NAMES = ["A_2chain", "B_seq128", "demo4", "C_greedy8x8", "E_64x2", "D_160m13b"]
 STOCHASTIC_TRACES = ["A_2chain", "B_seq128", "demo4", "E_64x2", "D_160m13b"]
 COMPACT_TRACES = ["V32k_seq128"]        # V = 32000, seeded weights, subsampled logits + full rows of the walked path
+# the headline dims (BASELINE.json configs[1] / [2]): 68m-dims draft -> Llama-2-7b-dims target, V = 32000, M = 384, 128-token
+# prompt; seeded weights (13.5 GB regenerated on the GPU box), compact logits.  B_7b: SpecTree on the
+# A100-CNN-68m-7b-stochastic growmap; C_7b: GreedyTree on 8x8-tree (+ recorded top-k / top-2 margins)
+HEADLINE_TRACES = ["B_7b", "C_7b"]
 BASELINE_TRACES = ["F_specinfer", "G_greedys"]        # the paper's comparison baselines (SpecInferTree, GreedySTree)
 
 

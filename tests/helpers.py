@@ -2,6 +2,8 @@
 speculation loop."""
 from __future__ import annotations
 
+import json
+
 import numpy as np
 import torch
 
@@ -30,7 +32,7 @@ def trace_state_dicts(z, meta):
         return state_dict_of(z, "draft"), state_dict_of(z, "target")
     from oracle import seeded_weights as SW
     sd_t = SW.seeded_state_dict(tuple(meta["target_dims"]), meta["vocab"], sm["target_seed"], meta["logit_gain"],
-                                  branch_scale=sm.get("branch_scale", 1.0))
+                                  branch_scale=sm.get("branch_scale", 1.0), lead=sm.get("lead"))
     sd_d = SW.seeded_state_dict(tuple(meta["draft_dims"]), meta["vocab"], sm["draft_seed"], meta["logit_gain"],
                                   branch_scale=sm.get("branch_scale", 1.0))
     if sm["share_vocab"] > 0.0:
@@ -40,14 +42,31 @@ def trace_state_dicts(z, meta):
     return sd_d, sd_t
 
 
+_BIG_ENGINES: dict = {}
+
+
 def build_engines(z, meta, device):
+    """Engines on a trace's weights.  The headline-dims traces (7B-dims target: a minute of CPU generation + 13.5 GB per
+    build) share ONE engine pair per process and seed set; it comes back with empty KV caches."""
     from sequoia_amd.Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
     M = meta["M"]
+    sm = meta.get("seeded")
+    big = bool(sm) and meta["target_dims"][0] * meta["target_dims"][1] * meta["target_dims"][2] > (1 << 30)
+    key = None
+    if big:
+        key = (str(device), tuple(meta["draft_dims"]), tuple(meta["target_dims"]), meta["vocab"], M, meta["logit_gain"],
+               json.dumps(sm, sort_keys=True))
+        if key in _BIG_ENGINES:
+            draft, target = _BIG_ENGINES[key]
+            draft.clear_kv(); target.clear_kv()
+            return draft, target
     sd_d, sd_t = trace_state_dicts(z, meta)
     dspec = dict(state_dict=sd_d, config=dims_dict(meta["draft_dims"], meta["vocab"]))
     tspec = dict(state_dict=sd_t, config=dims_dict(meta["target_dims"], meta["vocab"]))
     draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
     target = GraphInferenceEngineTG(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
+    if key is not None:
+        _BIG_ENGINES[key] = (draft, target)
     return draft, target
 
 
@@ -130,14 +149,62 @@ def check_replay(steps, z, meta, logit_tol=4e-2):
         ref_t = z[f"step{s}/target_logits"].astype(np.float32)
         stride = meta.get("compact") or 1          # compact traces keep every stride-th logit column
         internal = [t for t in ok if len(succ[t])]
-        dd = np.abs(rec["draft_logits"][internal][:, ::stride] - ref_d[internal]).max() if internal else 0.0
-        dt = np.abs(rec["target_logits"][ok][:, ::stride] - ref_t[ok]).max()
-        assert dd <= logit_tol and dt <= logit_tol, f"step {s}: logits off by {dd:.4f} / {dt:.4f}"
+        # tolerance: logit_tol absolute plus 4 fp16 ulps of the value (the headline-dims logits reach |x| ~ 40, where one
+        # fp16 ulp is 0.03)
+        def excess(got, ref):
+            return float((np.abs(got - ref) - np.abs(ref) * 2.0 ** -8).max())
+        dd = excess(rec["draft_logits"][internal][:, ::stride], ref_d[internal]) if internal else 0.0
+        dt = excess(rec["target_logits"][ok][:, ::stride], ref_t[ok])
+        assert dd <= logit_tol and dt <= logit_tol, f"step {s}: logits off by {dd:.4f} / {dt:.4f} beyond 4 ulps"
         if rec["accept_len"] == rec["ref_accept_len"] and np.array_equal(rec["valid"], rec["ref_valid"]):
             continue
-        assert meta["mode"] != "greedy", f"greedy step {s} must be bit-exact"
+        if meta["mode"] == "greedy":
+            # Greedy decisions are integer work and must be bit-exact -- unless the trace records the decision margins
+            # (headline-dims traces) and the FIRST decision that differs has a margin inside the logit tolerance asserted
+            # above: only then may a top-k cut, the order inside it, or an argmax legitimately fall the other way.
+            assert f"step{s}/draft_top_vals" in z.files, f"greedy step {s} must be bit-exact"
+            m, what = greedy_split_margin(rec, z, s, succ, parent)
+            assert m is not None and m < 2 * logit_tol, f"greedy step {s} leaves the reference at {what} (margin {m})"
+            print(f"greedy step {s}: margin-limited decision at {what} (margin {m:.4f})")
         return s, s
     return len(steps), None
+
+
+def greedy_split_margin(rec, z, s, succ, parent):
+    """The recorded margin of the first decision at which a greedy replay leaves the reference's step s: the draft
+    expansion (a child token differs: gap between the reference's draft logits at that rank and its neighbours) or the
+    walk (same tree, different accepted path: gap between the two largest target logits at the node where they part).
+    -> (margin, description) or (None, description)."""
+    gt, n = rec["gt"], len(succ)
+    got, ref = rec["tokens_pre"][gt - 1:gt + n - 1], rec["ref_tokens_pre"][gt - 1:gt + n - 1]
+    top = z[f"step{s}/draft_top_vals"]
+    for c in range(1, n):                                   # BFS order: parents precede children
+        if got[c] != ref[c] and all(got[a] == ref[a] for a in _ancestors(c, parent)):
+            p = parent[c]
+            j = succ[p].index(c)
+            vals = top[p][:len(succ[p]) + 1]
+            gaps = [abs(float(vals[j] - vals[j + 1]))] + ([abs(float(vals[j - 1] - vals[j]))] if j > 0 else [])
+            return min(gaps), f"child {j} of node {p} (draft top-k)"
+    # identical trees: the accepted paths part at the last common node
+    a_got, a_ref = rec["accept_len"] - gt, rec["ref_accept_len"] - gt
+    node = 0
+    ref_valid, got_valid = rec["ref_valid"], rec["valid"]
+    for i in range(min(a_got, a_ref)):
+        if got_valid[gt + i] != ref_valid[gt + i]:
+            break
+        nxt = [c for c in succ[node] if ref[c] == ref_valid[gt + i]]
+        if not nxt:
+            return None, f"node {node}: the reference's accepted token is not a child"
+        node = nxt[0]
+    return float(z[f"step{s}/target_top2_gap"][node]), f"node {node} (target argmax)"
+
+
+def _ancestors(c, parent):
+    out = []
+    while c in parent:
+        c = parent[c]
+        out.append(c)
+    return out
 
 
 def assert_replay_complete(name, steps, tree, z, meta, matched, diverged, commit_order="reference"):
@@ -152,7 +219,10 @@ def assert_replay_complete(name, steps, tree, z, meta, matched, diverged, commit
         assert matched == n_steps, f"{name}: replay stopped after {matched} of {n_steps} steps"
         return
     mode = meta["mode"]
-    assert mode != "greedy", f"{name}: greedy step {diverged} must be bit-exact"
+    if mode == "greedy":
+        # check_replay has asserted a recorded decision margin below the logit tolerance at this step
+        assert f"step{diverged}/draft_top_vals" in z.files, f"{name}: greedy step {diverged} must be bit-exact"
+        return
     rec = steps[diverged]
     succ, gt, n, T = meta["successors"], rec["gt"], len(meta["successors"]), meta["T"]
     dl, tl = rec["draft_logits"].astype(np.float16), rec["target_logits"].astype(np.float16)
@@ -187,3 +257,100 @@ def assert_replay_complete(name, steps, tree, z, meta, matched, diverged, commit
     tight = bool(margins) and min(abs(m) for m in margins) < 1e-3
     assert same or tight, (f"{name} step {diverged}: native decisions differ from the oracle on the native run's own "
                            f"inputs and no decision margin is below 1e-3 ({margins})")
+
+
+# ---- a prompt that ends on EOS in the middle of the device-driven loop ------------------------------------------------
+def rename_token(sd, x, eos=2):
+    """The same model with token ids x and eos exchanged (embedding and lm_head rows swapped)."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in ("model.embed_tokens.weight", "lm_head.weight"):
+        w = sd[k]
+        w[[x, eos]] = w[[eos, x]]
+    return sd
+
+
+def build_renamed(z, meta, device, x, step_graph=None):
+    """Engines + tree of a trace whose models call token x 'EOS' (id 2): the run becomes terminal the first time the
+    verifier accepts that token (Tree/SpecTree.py:208)."""
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
+    sd_d, sd_t = trace_state_dicts(z, meta)
+    if x is not None:
+        sd_d, sd_t = rename_token(sd_d, x), rename_token(sd_t, x)
+    M = meta["M"]
+    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dict(state_dict=sd_d, config=dims_dict(meta["draft_dims"], meta["vocab"])),
+                                 dtype=torch.float16, device=device)
+    target = GraphInferenceEngineTG(max_length=M, model_name_or_path=dict(state_dict=sd_t, config=dims_dict(meta["target_dims"], meta["vocab"])),
+                                    dtype=torch.float16, device=device)
+    prompt = z["prompt"].copy()
+    if x is not None:
+        is_x, is_e = prompt == x, prompt == 2
+        prompt[is_x], prompt[is_e] = 2, x
+
+    class _Z(dict):
+        files = list(z.files)
+    zz = _Z({k: z[k] for k in ("bonus_u24",) if k in z.files})
+    zz["prompt"] = prompt
+    for k in ("draw_u24", "target_u24"):
+        if k in z.files:
+            zz[k] = z[k]
+    tree = make_tree(zz, meta, draft, target, device, step_graph=step_graph)
+    return draft, target, tree
+
+
+def sync_run(tree, max_steps):
+    """[(accept_len, valid tokens, terminal)] of the synchronous API, until terminal / no room / max_steps."""
+    out = []
+    for _ in range(max_steps):
+        if tree._no_room:
+            break
+        tree.construct_grow_map()
+        valid, a, _, term = tree.verify()
+        out.append((int(a), valid.cpu().numpy().copy(), bool(term)))
+        if term:
+            break
+    return out
+
+
+def find_eos_case(z, meta, device, max_steps=6, min_step=2):
+    """A token x whose renaming to EOS ends the prompt at a step >= min_step (so that the device-driven loop has steps in
+    flight behind the terminal one).  Returns (x, synchronous run of the renamed model)."""
+    draft, target, tree = build_renamed(z, meta, device, None)
+    base = sync_run(tree, max_steps)
+    gts = [len(z["prompt"])] + [a + 1 for a, _, _ in base]
+    cands = []
+    for s, (a, valid, _) in enumerate(base):
+        if s >= min_step:
+            cands += [int(t) for t in valid[gts[s]:a] if int(t) not in (0, 2)]
+    early = {int(t) for s, (a, valid, _) in enumerate(base) if s < min_step for t in valid[:a + 1]}
+    for x in [c for c in dict.fromkeys(cands) if c not in early]:
+        draft, target, tree = build_renamed(z, meta, device, x)
+        run = sync_run(tree, max_steps)
+        if run and run[-1][2] and len(run) - 1 >= min_step:
+            return x, run
+    return None, None
+
+
+def pipelined_run(tree, max_steps, depth=2, horizon=None):
+    """The device-driven loop as harness.Loop drives it: step 0 synchronous (target prefill), then up to `depth` whole
+    steps in flight.  Returns ([(accept_len, terminal)], number of steps that were in flight behind the terminal one)."""
+    horizon = horizon or tree.max_length
+    tree.construct_grow_map()
+    valid, a, _, term = tree.verify()
+    out = [(int(a), bool(term))]
+    behind = 0
+    if term:
+        return out, behind
+    tree.begin_pipeline()
+    enq = 1
+    while len(out) < max_steps:
+        while len(tree._pipe["inflight"]) < depth and tree.can_enqueue(horizon) and enq < max_steps + depth:
+            tree.enqueue_step(); enq += 1
+        if not tree._pipe["inflight"]:
+            break
+        a, n_acc, bonus, term = tree.collect_step()
+        out.append((int(a), bool(term)))
+        if term:
+            behind = len(tree._pipe["inflight"])
+            break
+    tree.end_pipeline()
+    return out, behind

@@ -58,3 +58,23 @@ def test_pipelined_steps_equal_synchronous_steps(oracle_ops, name):
     if tree.ground_truth_len + tree.tree_size - 1 <= meta["M"]:
         tree.construct_grow_map()
         tree.verify()
+
+
+@pytest.mark.parametrize("name", ["C_greedy8x8", "D_160m13b"])
+def test_eos_inside_the_pipeline_keeps_the_finished_text(oracle_ops, name):
+    """A prompt that ends on an accepted EOS while another step is already in flight: the step behind the
+    terminal one must commit nothing -- tree.tokens[:a], the host mirrors and the KV offsets are those of the
+    synchronous run."""
+    from helpers import build_renamed, find_eos_case, pipelined_run
+    z, meta = load_trace(name)
+    x, want = find_eos_case(z, meta, "cpu")
+    assert x is not None, "no token of this trace ends the prompt at step >= 2 when renamed to EOS"
+    a_end = want[-1][0]
+    draft, target, tree = build_renamed(z, meta, "cpu", x, step_graph=True)
+    assert tree.state is not None
+    got, behind = pipelined_run(tree, max_steps=len(want) + 3)
+    assert [g[0] for g in got] == [w[0] for w in want] and got[-1][1]
+    assert behind >= 1, "the terminal step was collected with nothing in flight behind it: the case is not exercised"
+    assert np.array_equal(tree.tokens[:a_end].cpu().numpy(), want[-1][1])
+    assert tree.ground_truth_len == a_end
+    assert draft.engine.kv_cache.kv_offset == a_end and target.engine.kv_cache.kv_offset == a_end - 1

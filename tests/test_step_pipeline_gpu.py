@@ -23,7 +23,7 @@ def _sync_run(z, meta, n_steps):
     return out
 
 
-@pytest.mark.parametrize("name", ["demo4", "B_seq128", "D_160m13b", "C_greedy8x8", "V32k_seq128"])
+@pytest.mark.parametrize("name", ["demo4", "B_seq128", "D_160m13b", "C_greedy8x8", "V32k_seq128", "B_7b", "C_7b"])
 def test_step_graph_equals_synchronous_steps(name):
     z, meta = load_trace(name)
     n_steps = int(z["n_steps"])
@@ -71,3 +71,30 @@ def test_pipelined_loop_matches_synchronous_loop_on_config_b():
         loop.run_steps(40, on_accept=lambda a: lens.append(a))
         seqs.append(lens)
     assert seqs[0] == seqs[1] and len(seqs[0]) == 40
+
+
+@pytest.mark.parametrize("name", ["C_greedy8x8", "D_160m13b", "B_seq128"])
+def test_eos_inside_the_pipeline_keeps_the_finished_text(name):
+    """A prompt ends on an accepted EOS while the next whole-step graph is already in flight: the walker of that step
+    sees SQ_STEP_ACTIVE == 0 and commits nothing, the host drops its record -- tokens[:a], the host mirrors and the KV
+    offsets equal the synchronous run's (the overshoot step used to overwrite the committed text)."""
+    from helpers import build_renamed, find_eos_case, pipelined_run
+    z, meta = load_trace(name)
+    x, want = find_eos_case(z, meta, DEV)
+    assert x is not None, "no token of this trace ends the prompt at step >= 2 when renamed to EOS"
+    a_end = want[-1][0]
+    draft, target, tree = build_renamed(z, meta, DEV, x, step_graph=True)
+    assert tree.state is not None and tree.state.graph is not None
+    got, behind = pipelined_run(tree, max_steps=len(want) + 3)
+    torch.cuda.synchronize()
+    assert [g[0] for g in got] == [w[0] for w in want] and got[-1][1]
+    assert behind >= 1, "nothing was in flight behind the terminal step: the case is not exercised"
+    assert np.array_equal(tree.tokens[:a_end].cpu().numpy(), want[-1][1])
+    assert tree.ground_truth_len == a_end
+    assert draft.engine.kv_cache.kv_offset == a_end and target.engine.kv_cache.kv_offset == a_end - 1
+    # the committed KV rows survive too: the target cache of the pipelined run equals the synchronous run's on [0, a - 1)
+    d2, t2, tree2 = build_renamed(z, meta, DEV, x)
+    from helpers import sync_run
+    sync_run(tree2, len(want))
+    ka, kb = target.engine.kv_cache.k_cache[..., :a_end - 1, :], t2.engine.kv_cache.k_cache[..., :a_end - 1, :]
+    assert torch.equal(ka, kb)

@@ -1,0 +1,158 @@
+"""The two-shot all-reduce over peer-mapped buffers (csrc/allreduce.hip, Engine/xgmi_allreduce.py) with two ranks on the
+ONE GPU of the test box: the workspaces are hipIpc-exported / -opened across the two processes exactly as they are across
+GPUs, every flag and every peer store of the protocol runs, the transport of the setup is gloo.  Checked: sums against
+gloo's all-reduce for sizes from 8 elements to the [129, 8192] message of the 70B verify, bit-identical rows on both ranks,
+back-to-back calls without host synchronisation and with skewed arrival (epoch protocol), replay from a hipGraph, the
+tensor-parallel target engine on it (every step of the reference's trace), and a bounded spin when the peer never shows up.
+(N real GPUs: bench.py --gpus N reports `allreduce` for configuration E.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _ar_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO); sys.path.insert(0, HERE)
+    import time
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    from sequoia_amd.Engine.xgmi_allreduce import XgmiAllReduce
+    ar = XgmiAllReduce.create(None, dev, max_elems=144 * 8192)
+    assert ar is not None, "xGMI all-reduce could not be set up on this box (see stderr)"
+    res = dict(sizes=[], graph=False, burst=False)
+    gen = torch.Generator(device="cpu")
+    # 1. sizes, against gloo's sum (fp32 reference of the fp16 inputs), bit-identical across ranks
+    for i, n in enumerate([8, 64, 2056, 34 * 768, 128 * 4096, 129 * 8192, 144 * 8192]):
+        gen.manual_seed(77 * i + rank)
+        x = (torch.randn(n, generator=gen) * 3).half().to(dev)
+        want = x.float()
+        dist.all_reduce(want)
+        got = ar(x.clone())
+        torch.cuda.synchronize()
+        assert ar.status() == 0
+        # one rounding of an fp32 sum: within half an fp16 ulp of the exact sum
+        err = (got.float() - want).abs()
+        tol = want.abs().clamp(min=1.0) * 2.0 ** -10
+        assert bool((err <= tol).all()), f"n = {n}: max err {float(err.max())}"
+        bits = got.view(torch.int16).to(torch.int32)
+        lo, hi = bits.clone(), bits.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), f"n = {n}: ranks hold different bits"
+        res["sizes"].append(n)
+    # 2. a burst of back-to-back calls without host synchronisation, arrival skewed (one rank is kept busy / asleep):
+    #    call k + 1 of the fast rank must not disturb call k of the slow one (per-block epochs, areas reused every call)
+    n = 129 * 8192
+    xs, wants = [], []
+    for k in range(24):
+        gen.manual_seed(5000 + 31 * k + rank)
+        x = (torch.randn(n, generator=gen)).half().to(dev)
+        w = x.float(); dist.all_reduce(w)
+        xs.append(x); wants.append(w)
+    torch.cuda.synchronize(); dist.barrier()
+    big = torch.randn(4096, 4096, device=dev)
+    for k in range(24):
+        if k % 5 == rank:
+            time.sleep(0.02)                       # host-side skew
+        if k % 7 == 3 * rank:
+            big = big @ big * 1e-4                 # device-side skew: this rank's kernel is queued behind a GEMM
+        ar(xs[k])
+    torch.cuda.synchronize()
+    assert ar.status() == 0
+    for k in range(24):
+        err = (xs[k].float() - wants[k]).abs()
+        assert bool((err <= wants[k].abs().clamp(min=1.0) * 2.0 ** -10).all()), f"burst call {k}"
+    res["burst"] = True
+    # 3. three all-reduces inside one hipGraph, replayed on fresh data (the launch has no per-call argument)
+    bufs = [torch.zeros(129 * 1024, dtype=torch.float16, device=dev) for _ in range(3)]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for b in bufs:
+            ar(b)
+        s.synchronize()
+    torch.cuda.current_stream().wait_stream(s)
+    dist.barrier()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for b in bufs:
+            ar(b)
+    for rep in range(4):
+        wants = []
+        for j, b in enumerate(bufs):
+            gen.manual_seed(9000 + 10 * rep + j + 100 * rank)
+            v = torch.randn(b.numel(), generator=gen).half().to(dev)
+            b.copy_(v)
+            w = v.float(); dist.all_reduce(w); wants.append(w)
+        torch.cuda.synchronize(); dist.barrier()
+        g.replay()
+        torch.cuda.synchronize()
+        assert ar.status() == 0
+        for b, w in zip(bufs, wants):
+            assert bool(((b.float() - w).abs() <= w.abs().clamp(min=1.0) * 2.0 ** -10).all()), f"graph replay {rep}"
+    res["graph"] = True
+    np.save(os.path.join(out_dir, f"ar{rank}.npy"), np.array([len(res["sizes"]), int(res["burst"]), int(res["graph"]), ar.calls]))
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+
+
+def test_two_shot_allreduce_two_ranks_one_gpu(tmp_path):
+    port = 33100 + (os.getpid() % 1500)
+    mp.spawn(_ar_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        sizes, burst, graph, calls = np.load(tmp_path / f"ar{r}.npy")
+        assert sizes == 7 and burst == 1 and graph == 1 and calls > 40
+
+
+def _lonely_worker(rank, world, port, out_dir):
+    """Rank 1 never launches: rank 0's kernel must give up after its bounded spin and say so."""
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from sequoia_amd.Engine.xgmi_allreduce import XgmiAllReduce
+    ar = XgmiAllReduce.create(None, "cuda:0", max_elems=4096, self_check=False)
+    assert ar is not None
+    if rank == 0:
+        x = torch.ones(4096, dtype=torch.float16, device="cuda:0")
+        ar(x)
+        torch.cuda.synchronize()                         # returns: the spin is bounded
+        np.save(os.path.join(out_dir, "lonely.npy"), np.array([ar.status()]))
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+
+
+def test_missing_peer_times_out_instead_of_hanging(tmp_path, monkeypatch):
+    monkeypatch.setenv("SEQUOIA_AR_SPIN_LIMIT", "200000")        # ~0.3 s instead of the production bound of a few seconds
+    port = 34700 + (os.getpid() % 1500)
+    mp.spawn(_lonely_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert int(np.load(tmp_path / "lonely.npy")[0]) & 1 == 1
+
+
+@pytest.mark.parametrize("name", ["E_64x2"])
+def test_tp2_on_the_xgmi_allreduce_matches_reference_trace(name, tmp_path, monkeypatch):
+    """The tensor-parallel target (KV-head split, vocabulary-parallel lm_head) with its row-parallel projections reduced
+    by the xGMI kernel: every step of the reference's trace on both ranks (tests/test_tp_gloo_cpu.py::_worker asserts
+    identical decisions on both ranks)."""
+    from test_tp_gloo_cpu import _worker
+    monkeypatch.setenv("SEQUOIA_TP_ALLREDUCE", "xgmi")
+    monkeypatch.setenv("SEQUOIA_TP_REQUIRE_XGMI", "1")
+    port = 36300 + (os.getpid() % 1500)
+    mp.spawn(_worker, args=(2, port, name, str(tmp_path), "cuda:0"), nprocs=2, join=True)
+    for r in range(2):
+        matched, diverged = np.load(tmp_path / f"r{r}.npy")
+        assert diverged == -1 and matched == 2, f"rank {r}: {matched} steps, diverged at {diverged}"
