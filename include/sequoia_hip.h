@@ -386,6 +386,20 @@ int sq_ar_status(const void* own_ws, int* status);      /* 0 ok; bit 0 / 1: a ph
 int sq_allreduce_sum_f16(void* data, size_t n, int rank, int world, void* const* ws, size_t max_elems, int blocks,
                          void* stream);
 
+/* ---- f1: RMSNorm folded into the projection that consumes it (small draft models) ------------------------------
+ * out = epilogue( (RMSNorm(x) * norm_weight) . w^T ) for m <= 48 rows and k <= 1024 (the 68m / 160m drafts): every
+ * workgroup normalises the whole activation block itself into LDS, so the separate norm launch in front of
+ * q/k/v_proj, gate/up_proj and lm_head (Engine/Llama_modules.py:282-288,341-346; Engine/Llama_model.py:280-283)
+ * disappears.  x: the residual stream [m][k] fp16 row-major -- or, first layer, d_ids != NULL: row r is
+ * embed[d_ids[r]] (Engine/Llama_model.py:151), written to x_out [m][k] when x_out != NULL.  w_frag: the
+ * fragment-major weight image of sq_repack_linear_weight_f16 (swiglu: gate tiles then up tiles).  swiglu == 0: out is
+ * fp16 [m][ldo]; swiglu != 0: out is the fragment-major image [n_out/32][ceil(m/16)][64][8] of
+ * h(h(silu(h(g))) * h(u)) (:271).  tiles workgroups share the n_out / 16 column units (<= 8 per workgroup; swiglu <= 2).
+ * Rounding points are those of sq_rmsnorm_f16 + sq_linear_ts_f16; only fp32 summation orders differ.                */
+int sq_norm_linear_f16(const void* x, const int64_t* d_ids, const void* embed, int vocab, void* x_out,
+                       const void* norm_weight, float eps, const void* w_frag, void* out, int ldo, int m, int n_out,
+                       int k, int swiglu, int tiles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

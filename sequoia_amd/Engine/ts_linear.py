@@ -300,11 +300,63 @@ def assert_same_plans_across_ranks(*models, group=None):
         raise RuntimeError(f"launch plans differ between tensor-parallel ranks: {sigs}")
 
 
+# Small draft models (hidden <= 1024, <= 48 rows: every level of the 68m / 160m drafts): the RMSNorm in front of qkv,
+# gate_up and lm_head is computed inside the projection (csrc/draft_fused.hip) and o_proj / down_proj write the residual
+# stream through the "+ residual" epilogue -- 14 launches per 2-layer forward instead of 19.  SEQUOIA_DRAFT_FUSED=0 keeps
+# the general tall-skinny sequence.
+SMALL_FUSED = os.environ.get("SEQUOIA_DRAFT_FUSED", "1") != "0"
+SMALL_MAX_ROWS, SMALL_MAX_HIDDEN = 48, 1024
+
+
+def small_fused_ok(model, ts: "TsLinearSet", q_len: int) -> bool:
+    d = model.dims
+    return (SMALL_FUSED and q_len <= SMALL_MAX_ROWS and d.hidden_size <= SMALL_MAX_HIDDEN and model.reduce_fn is None
+            and model.gather_logits_fn is None and not ts.exclusive and ts.shapes["down"][1] % 32 == 0
+            and d.tp_world == 1)
+
+
+def forward_small_fused(model, ts: "TsLinearSet", ids, q_len, pos, storage_ids, dense, tree, kv_cache, logits_out=None):
+    """forward_ts for a small draft: per layer  norm+qkv | RoPE + KV write | tree attention | o_proj + residual |
+    norm+gate_up+SwiGLU | down_proj + residual,  then norm+lm_head (optionally straight into `logits_out`, the tree's
+    draft_logits rows).  Same rounding points as forward_ts; fp32 summation orders differ (K is not split across
+    workgroups here)."""
+    from .Llama_modules import attention_core
+    ops = get_ops()
+    W, dims = model.weights, model.dims
+    eps = dims.rms_norm_eps
+    dev, dt = W.embed.device, W.embed.dtype
+    hidden = dims.hidden_size
+    n_qkv = ts.shapes["qkv"][0]
+    hd = ts.shapes["o"][1]
+    inter = ts.shapes["down"][1]
+    vocab = ts.shapes["lm_head"][0]
+    ids = ids.contiguous()
+    x = torch.empty((q_len, hidden), dtype=dt, device=dev)           # the residual stream
+    for li, lw in enumerate(W.layers):
+        qkv = torch.empty((q_len, n_qkv), dtype=dt, device=dev)
+        if li == 0:
+            ops.norm_linear(None, lw.ln1, eps, ts.frag("qkv", li), qkv, q_len, n_qkv, hidden, tiles=n_qkv // 16, ids=ids,
+                            embed=W.embed, x_out=x)
+        else:
+            ops.norm_linear(x, lw.ln1, eps, ts.frag("qkv", li), qkv, q_len, n_qkv, hidden, tiles=n_qkv // 16)
+        attn = attention_core(qkv, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree, out_frag=True)
+        ops.linear_ts(attn, ts.frag("o", li), q_len, hidden, hd, out=x, res=x, tiles=hidden // 16, splits=1)
+        act = torch.empty(ops.frag_shape(q_len, inter), dtype=dt, device=dev)
+        ops.norm_linear(x, lw.ln2, eps, ts.frag("gate_up", li), act, q_len, inter, hidden, swiglu=True, tiles=inter // 16)
+        ops.linear_ts(act, ts.frag("down", li), q_len, hidden, inter, out=x, res=x, tiles=hidden // 16, splits=1)
+    kv_cache.note_written(q_len)
+    logits = logits_out if logits_out is not None else torch.empty((q_len, vocab), dtype=dt, device=dev)
+    ops.norm_linear(x, W.norm, eps, ts.frag("lm_head"), logits, q_len, vocab, hidden, tiles=(vocab // 16 + 7) // 8)
+    return logits.unsqueeze(0)
+
+
 def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree, kv_cache):
     """Decoder forward of <= MAX_ROWS tree tokens on the tall-skinny projections.  ids: int64 [q] token ids.
     Returns logits [1, q, V].  Tensor-parallel shards (model.reduce_fn set): the partial output of the row-parallel
     projections (o_proj, down_proj) is reduced across ranks before the residual add; the vocabulary-parallel logits
     are gathered at the end (model.gather_logits_fn)."""
+    if small_fused_ok(model, ts, q_len):
+        return forward_small_fused(model, ts, ids, q_len, pos, storage_ids, dense, tree, kv_cache)
     from .Llama_modules import attention_core
     ops = get_ops()
     W, dims = model.weights, model.dims

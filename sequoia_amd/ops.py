@@ -430,6 +430,27 @@ class HipOps:
               "sq_linear_ts_f16")
         return slab if splits > 1 else out
 
+    def norm_linear(self, x, norm_weight, eps, w_frag, out, m, n_out, k, swiglu=False, tiles=256, ids=None, embed=None,
+                    x_out=None):
+        """out = epilogue((RMSNorm(x) * norm_weight) . w^T), the norm computed inside the projection (m <= 48, k <= 1024).
+        ids / embed: first layer, x = embed[ids] (x_out receives the residual stream)."""
+        _need(norm_weight, torch.float16, "norm_weight"); _need(w_frag, torch.float16, "w_frag")
+        _need(out, torch.float16, "out", contiguous=swiglu)
+        if ids is not None:
+            _need(ids, torch.int64, "ids"); _need(embed, torch.float16, "embed")
+            assert ids.numel() >= m and embed.shape[1] == k
+            if x_out is not None:
+                _need(x_out, torch.float16, "x_out")
+        else:
+            _need(x, torch.float16, "x")
+            assert x.numel() >= m * k
+        ldo = n_out if swiglu else out.stride(0)
+        check(self.lib.sq_norm_linear_f16(_ptr(x), _ptr(ids), _ptr(embed), 0 if embed is None else embed.shape[0], _ptr(x_out),
+                                          norm_weight.data_ptr(), float(eps), w_frag.data_ptr(), out.data_ptr(), ldo, int(m),
+                                          int(n_out), int(k), 1 if swiglu else 0, int(tiles), self._stream()),
+              "sq_norm_linear_f16")
+        return out
+
     def add_rmsnorm_slabs(self, slab, splits, residual, sum_out, weight, out, eps, out_frag=False):
         """x = h(sum of the split-K partials); sum_out = x + residual; out = RMSNorm(sum_out) * weight
         (out None: add only)."""

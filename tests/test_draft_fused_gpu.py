@@ -1,0 +1,170 @@
+"""Small-draft fusion (csrc/draft_fused.hip, Engine/ts_linear.py::forward_small_fused): the RMSNorm computed inside the
+projection that consumes it, the residual stream written by the o_proj / down_proj epilogue.  Kernel level against the
+numpy oracle's rmsnorm + linear (the reference's rounding points), forward level against the unfused tall-skinny sequence
+and the general (hipBLASLt + glue) path on the 68m architecture; the end-to-end traces (tests/test_e2e_gpu.py) run their
+draft levels through it by default."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_np as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sequoia_amd.ops import HipOps
+    return HipOps()
+
+
+def _rmsnorm_ref(x16, g16, eps):
+    xf = x16.astype(np.float32)
+    var = (xf * xf).mean(-1, keepdims=True, dtype=np.float32)
+    nrm = O.h(xf * (np.float32(1.0) / np.sqrt(var + np.float32(eps))))
+    return O.h(O.f(g16) * O.f(nrm))
+
+
+@pytest.mark.parametrize("m,k,n,tiles", [(1, 768, 2304, 144), (19, 768, 2304, 144), (34, 768, 2304, 72), (48, 1024, 512, 32),
+                                          (34, 768, 32000, 250), (7, 256, 1024, 8)])
+def test_norm_linear_plain_matches_oracle(hip, m, k, n, tiles):
+    rng = np.random.RandomState(m * 7 + n)
+    x = (rng.randn(m, k) * 0.7).astype(np.float16)
+    g = (1.0 + 0.1 * rng.randn(k)).astype(np.float16)
+    w = (rng.randn(n, k) * 0.05).astype(np.float16)
+    eps = 1e-6
+    a = _rmsnorm_ref(x, g, eps)
+    want = a.astype(np.float32) @ w.astype(np.float32).T                      # fp32 reference of the fp16 operands
+    out = torch.full((m, n), 7.0, dtype=torch.float16, device=DEV)
+    wf = hip.repack_weight(torch.from_numpy(w).to(DEV))
+    hip.norm_linear(torch.from_numpy(x).to(DEV), torch.from_numpy(g).to(DEV), eps, wf, out, m, n, k, tiles=tiles)
+    got = out.float().cpu().numpy()
+    # the normalised operand may differ from the oracle's by one fp16 ulp in a few entries (sum-of-squares order); the
+    # product is compared with the tolerance of an fp16 rounding of the result plus that input noise
+    tol = np.abs(want) * 2.0 ** -10 + 2e-2
+    assert np.all(np.abs(got - want) <= tol), float(np.abs(got - want).max())
+    # exactness where it must hold: the unfused kernels on the same inputs agree to the last bit in >= 99.9 % of the entries
+    h = torch.empty(hip.frag_shape(m, k), dtype=torch.float16, device=DEV)
+    hip.rmsnorm_frag(torch.from_numpy(x).to(DEV), torch.from_numpy(g).to(DEV), h, eps)
+    ref = torch.empty((m, n), dtype=torch.float16, device=DEV)
+    hip.linear_ts(h, wf, m, n, k, out=ref, tiles=min(tiles, n // 16))
+    same = (ref == out).float().mean().item()
+    assert same > 0.98, same
+
+
+def test_norm_linear_embedding_and_residual_stream(hip):
+    rng = np.random.RandomState(3)
+    V, k, n, m = 5000, 768, 2304, 27
+    emb = (rng.randn(V, k) * 0.5).astype(np.float16)
+    ids = rng.randint(0, V, size=m).astype(np.int64)
+    ids[3] = V + 10                                                           # clamped like sq_embed_rmsnorm_f16
+    g = (1.0 + 0.1 * rng.randn(k)).astype(np.float16)
+    w = (rng.randn(n, k) * 0.05).astype(np.float16)
+    wf = hip.repack_weight(torch.from_numpy(w).to(DEV))
+    x_out = torch.zeros((m, k), dtype=torch.float16, device=DEV)
+    out = torch.empty((m, n), dtype=torch.float16, device=DEV)
+    hip.norm_linear(None, torch.from_numpy(g).to(DEV), 1e-6, wf, out, m, n, k, tiles=144, ids=torch.from_numpy(ids).to(DEV),
+                    embed=torch.from_numpy(emb).to(DEV), x_out=x_out)
+    rows = emb[np.clip(ids, 0, V - 1)]
+    assert np.array_equal(x_out.cpu().numpy(), rows)                          # the residual stream: exact copy
+    out2 = torch.empty_like(out)
+    hip.norm_linear(torch.from_numpy(rows).to(DEV), torch.from_numpy(g).to(DEV), 1e-6, wf, out2, m, n, k, tiles=144)
+    assert torch.equal(out, out2)                                             # same arithmetic with or without the gather
+
+
+@pytest.mark.parametrize("m", [1, 16, 34])
+def test_norm_linear_swiglu_matches_unfused_kernels(hip, m):
+    rng = np.random.RandomState(11 + m)
+    k, inter = 768, 3072
+    x = (rng.randn(m, k) * 0.7).astype(np.float16)
+    g = (1.0 + 0.1 * rng.randn(k)).astype(np.float16)
+    w = (rng.randn(2 * inter, k) * 0.04).astype(np.float16)                    # gate rows | up rows
+    wf = hip.repack_weight(torch.from_numpy(w).to(DEV))
+    xd, gd = torch.from_numpy(x).to(DEV), torch.from_numpy(g).to(DEV)
+    act = torch.zeros(hip.frag_shape(m, inter), dtype=torch.float16, device=DEV)
+    hip.norm_linear(xd, gd, 1e-6, wf, act, m, inter, k, swiglu=True, tiles=inter // 16)
+    # oracle: rmsnorm -> fp32 product -> h(h(silu(h(g))) * h(u)), then the fragment-major image of it
+    a = _rmsnorm_ref(x, g, 1e-6).astype(np.float32)
+    gu = a @ w.astype(np.float32).T
+    gate, up = O.h(gu[:, :inter]), O.h(gu[:, inter:])
+    s = O.h(O.f(gate) / (np.float32(1.0) + np.exp(-O.f(gate))))
+    want = O.h(O.f(s) * O.f(up)).astype(np.float32)
+    # un-fragment the kernel's image: [inter/32][mtp][64][8], lane = (c % 4) * 16 + row % 16
+    img = act.cpu().numpy()
+    got = np.zeros((m, inter), dtype=np.float32)
+    for r in range(m):
+        lanes = (np.arange(inter // 8) % 4) * 16 + (r % 16)
+        got[r] = img[np.arange(inter // 8) // 4, r // 16, lanes].reshape(-1)
+    tol = np.abs(want) * 2.0 ** -9 + 1.5e-2
+    assert np.all(np.abs(got - want) <= tol), float(np.abs(got - want).max())
+    # rows beyond m inside the last tile are zeros (the down projection multiplies them)
+    mtp = (m + 15) // 16
+    if m % 16:
+        pad = img[:, mtp - 1, :, :].reshape(inter // 32, 4, 16, 8)[:, :, m % 16:, :]
+        assert not pad.any()
+
+
+def test_fused_draft_forward_matches_unfused_and_general_path():
+    """68m architecture, a 34-token tree level after a 126-token prefill: the fused sequence, the tall-skinny sequence and
+    the general path give the same logits up to accumulation order, and the same KV rows."""
+    from sequoia_amd.Engine import ts_linear
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine
+    from sequoia_amd.Engine.Llama_modules import TreeContext
+    from sequoia_amd.growmap import GrowMap
+    M = 384
+    eng = GraphInferenceEngine(max_length=M, model_name_or_path="random:JackFram/llama-68m:seed=5:gain=20",
+                               dtype=torch.float16, device=DEV)
+    g = GrowMap.load("A100-CNN-68m-7b-stochastic")
+    bm = g.device_tensors(DEV)["bitmask"]
+    torch.manual_seed(0)
+    ids = torch.randint(3, 32000, (1, 161), device=DEV)
+    model = eng.engine.model
+    ts = model.ts
+    assert ts is not None and ts_linear.small_fused_ok(model, ts, 34)
+    outs, caches = {}, {}
+    pos = torch.arange(161, device=DEV)
+    for mode in ("fused", "ts", "general"):
+        ts_linear.SMALL_FUSED = mode == "fused"
+        model.ts = None if mode == "general" else ts
+        eng.clear_kv()
+        eng.inference(input_ids=ids[:, :126], storage_ids=pos[:126], position_ids=pos[None, :126], attn_mask=None,
+                      tree=TreeContext(0, 126, g.size, bm, 126))
+        lv = eng.inference(input_ids=ids[:, 126:160], storage_ids=pos[126:160], position_ids=pos[None, 126:160],
+                           attn_mask=None, tree=TreeContext(126, 126, g.size, bm, 160))
+        one = eng.inference(input_ids=ids[:, 160:161], storage_ids=pos[160:161], position_ids=pos[None, 160:161],
+                            attn_mask=None, tree=TreeContext(160, 161, g.size, bm, 161))
+        outs[mode] = (lv.float().clone(), one.float().clone())
+        caches[mode] = (eng.engine.kv_cache.k_cache[:, :, :, :161].float().clone(), eng.engine.kv_cache.v_cache[:, :, :, :161].float().clone())
+    ts_linear.SMALL_FUSED = True
+    model.ts = ts
+    for other in ("ts", "general"):
+        for a, b in zip(outs["fused"], outs[other]):
+            assert (a - b).abs().max() < 6e-2, (other, float((a - b).abs().max()))       # logits of magnitude ~10
+            assert (a.argmax(-1) == b.argmax(-1)).float().mean() > 0.9
+        for a, b in zip(caches["fused"], caches[other]):
+            assert (a - b).abs().max() < 2e-2
+
+
+def test_fused_draft_forward_replays_from_a_graph():
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine
+    from sequoia_amd.Engine.Llama_modules import TreeContext
+    from sequoia_amd.growmap import GrowMap
+    M = 384
+    eng = GraphInferenceEngine(max_length=M, model_name_or_path="random:JackFram/llama-68m:seed=6:gain=20",
+                               dtype=torch.float16, device=DEV)
+    g = GrowMap.load("A100-CNN-68m-7b-stochastic")
+    bm = g.device_tensors(DEV)["bitmask"]
+    eng.initialize_cuda_graph([19], tree_bitmask=bm, n_tree=g.size)
+    torch.manual_seed(1)
+    ids = torch.randint(3, 32000, (1, 60), device=DEV)
+    pos = torch.arange(60, device=DEV)
+    res = []
+    for use_graph in (False, True):
+        eng.clear_kv()
+        eng.inference(input_ids=ids[:, :41], storage_ids=pos[:41], position_ids=pos[None, :41], attn_mask=None,
+                      tree=TreeContext(0, 41, g.size, bm, 41, contiguous_slots=True))
+        run = eng.graph_inference if use_graph else eng.inference
+        res.append(run(input_ids=ids[:, 41:60], storage_ids=pos[41:60], position_ids=pos[None, 41:60], attn_mask=None,
+                       tree=TreeContext(41, 41, g.size, bm, 60, contiguous_slots=True)).clone())
+    assert torch.equal(res[0], res[1])

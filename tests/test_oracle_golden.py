@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 
 from conftest import COMPACT_TRACES, GOLDEN, STOCHASTIC_TRACES, TRACE_NAMES, load_trace
+
+COMPACT_STOCHASTIC = COMPACT_TRACES + ["B_7b"]        # + the headline-dims SpecTree trace (68m -> 7B dims)
 from oracle import ops_np as O
 
 
@@ -120,7 +122,7 @@ def test_verify_stochastic_matches_reference(name):
             assert np.abs(a16 - b16).max() <= 2
 
 
-@pytest.mark.parametrize("name", COMPACT_TRACES)
+@pytest.mark.parametrize("name", COMPACT_STOCHASTIC)
 def test_verify_stochastic_matches_reference_full_vocab(name):
     """V = 32000: the oracle's verifier on the reference's own logits.  The trace keeps the full target / draft rows
     of the nodes the reference walked (the verifier touches no other row) and every step must reproduce the
@@ -149,7 +151,7 @@ def test_verify_stochastic_matches_reference_full_vocab(name):
     assert sum(m <= 0 for m in margins) >= 3 and sum(m > 0 for m in margins) >= 3
 
 
-@pytest.mark.parametrize("name", COMPACT_TRACES)
+@pytest.mark.parametrize("name", COMPACT_STOCHASTIC)
 def test_sampler_matches_reference_full_vocab(name):
     """V = 32000: sampling without replacement of every tree level of step 0 against the reference's outputs.  The
     level's input rows are the trace's draft rows where they were kept (root row); the noise is regenerated from the
@@ -175,6 +177,29 @@ def test_sampler_matches_reference_full_vocab(name):
                 assert keys[got[c]] == keys[want[c]], f"{name} step {s} rank {c}"
         checked += 1
     assert checked >= 3
+
+
+def test_verify_greedy_matches_reference_headline_dims():
+    """C_7b (GreedyTree, 8x8 growmap, 68m -> 7B dims, V = 32000): the oracle's greedy walk on the reference's own target
+    rows of the walked nodes (the only rows it reads) reproduces the accepted tokens of every step."""
+    z, meta = load_trace("C_7b")
+    succ = meta["successors"]
+    n, V = len(succ), meta["vocab"]
+    accepted = 0
+    for s in range(int(z["n_steps"])):
+        gt = int(z[f"step{s}/gt"])
+        nodes = z[f"step{s}/path_nodes"]
+        tl = np.full((n, V), -60000.0, dtype=np.float16)
+        tl[nodes] = z[f"step{s}/path_target_rows"]
+        tokens = z[f"step{s}/tokens_pre"].copy()
+        # rows off the walked path are never compared by the walk: give them an argmax no child carries
+        tl[[t for t in range(n) if t not in set(nodes.tolist())], 1] = 1.0
+        res = O.verify_greedy(tl, tokens, succ, gt)
+        assert res["accept_len"] == int(z[f"step{s}/accept_len"]), f"step {s}"
+        valid = z[f"step{s}/valid_tokens"]
+        assert np.array_equal(tokens[:valid.shape[0]], valid), f"step {s}"
+        accepted += res["n_tree"]
+    assert accepted >= 1
 
 
 def test_verify_greedy_matches_reference():
