@@ -372,11 +372,11 @@ int sq_add_rmsnorm_slabs_f16(const void* slab, int splits, const void* residual,
  * ranks get bit-identical rows), all-gather by direct peer stores; flags carry a device-resident epoch, so the launch
  * replays from a hipGraph.  Stream-ordered, no host synchronisation, every spin bounded (sq_ar_status reports a
  * timeout instead of hanging).  RCCL (torch.distributed) remains the fallback.
- *   setup, once per rank: ws = sq_ar_alloc(sq_ar_workspace_bytes(world, max_elems)) (uncached device memory, zeroed),
+ *   setup, once per rank: ws = sq_ar_alloc(sq_ar_workspace_bytes(world, max_elems, max_gather_elems)) (uncached, zeroed),
  *   sq_ar_ipc_export(ws, handle) -> exchange the 64-byte handles (any transport) -> sq_ar_ipc_open(peer handle);
  *   call: ws[world] = every rank's workspace as mapped in the calling process (ws[rank] = own), identical n / blocks
  *   on all ranks, n % 8 == 0, n <= max_elems; blocks <= 0 picks one block per 4 KB of a chunk (max 64).             */
-size_t sq_ar_workspace_bytes(int world, size_t max_elems);
+size_t sq_ar_workspace_bytes(int world, size_t max_elems, size_t max_gather_elems);
 int sq_ar_alloc(void** ptr, size_t bytes);
 int sq_ar_free(void* ptr);
 int sq_ar_ipc_export(void* ptr, void* handle64);
@@ -385,9 +385,15 @@ int sq_ar_ipc_close(void* ptr);
 int sq_ar_status(const void* own_ws, int* status);      /* 0 ok; bit 0 / 1: a phase-1 / phase-2 flag never arrived (host sync) */
 int sq_allreduce_sum_f16(void* data, size_t n, int rank, int world, void* const* ws, size_t max_elems, int blocks,
                          void* stream);
+/* All-gather of the vocabulary-parallel lm_head (column-parallel over the ranks, Engine/Llama_model.py:280-283 on a
+ * shard): slice = this rank's [rows][v] fp16 logits, out = the full [rows][world v] rows (rank r's columns at
+ * [r v, (r + 1) v)), by direct peer stores into the same workspaces (their own area: rows world v <=
+ * max_gather_elems, the value the workspace was sized with).  v % 8 == 0.                                          */
+int sq_allgather_cols_f16(const void* slice, void* out, int rows, int v, int rank, int world, void* const* ws,
+                          size_t max_elems, size_t max_gather_elems, void* stream);
 
 /* ---- f1: RMSNorm folded into the projection that consumes it (small draft models) ------------------------------
- * out = epilogue( (RMSNorm(x) * norm_weight) . w^T ) for m <= 48 rows and k <= 1024 (the 68m / 160m drafts): every
+ * out = epilogue( (RMSNorm(x) * norm_weight) . w^T ) for m <= 48 rows and k in {256, 512, 768, 1024} (the 68m / 160m drafts): every
  * workgroup normalises the whole activation block itself into LDS, so the separate norm launch in front of
  * q/k/v_proj, gate/up_proj and lm_head (Engine/Llama_modules.py:282-288,341-346; Engine/Llama_model.py:280-283)
  * disappears.  x: the residual stream [m][k] fp16 row-major -- or, first layer, d_ids != NULL: row r is

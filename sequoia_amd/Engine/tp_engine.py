@@ -38,7 +38,8 @@ class _TPInner(InferenceEngineTG):
         if world > 1 and ALLREDUCE == "xgmi":
             from .ts_linear import MAX_ROWS
             from .xgmi_allreduce import XgmiAllReduce
-            self.xgmi = XgmiAllReduce.create(group, device, max_elems=MAX_ROWS * self.model.dims.hidden_size)
+            self.xgmi = XgmiAllReduce.create(group, device, max_elems=MAX_ROWS * self.model.dims.hidden_size,
+                                             max_gather_elems=MAX_ROWS * self.model.dims.vocab_size)
             if self.xgmi is None and str(device).startswith("cuda") and os.environ.get("SEQUOIA_TP_REQUIRE_XGMI", "0") == "1":
                 raise RuntimeError("SEQUOIA_TP_REQUIRE_XGMI=1 but the xGMI all-reduce could not be set up (see stderr)")
         if world > 1 or FORCE_HOOKS:
@@ -55,6 +56,11 @@ class _TPInner(InferenceEngineTG):
         return x
 
     @property
+    def collectives_capturable(self):
+        """True when a tree forward issues no torch.distributed call at all (both collectives on the xGMI kernels)."""
+        return self.xgmi is not None
+
+    @property
     def allreduce_kind(self):
         return "xgmi two-shot (peer-mapped buffers)" if self.xgmi is not None else "rccl"
 
@@ -65,6 +71,8 @@ class _TPInner(InferenceEngineTG):
             return logits
         q, v = logits.shape
         logits = logits.contiguous()
+        if self.xgmi is not None and self.xgmi.fits_gather(logits):
+            return self.xgmi.gather_cols(logits)          # one kernel: every rank stores its columns into every peer
         if logits.device.type == "cuda":
             out = torch.empty((self.world * q, v), dtype=logits.dtype, device=logits.device)   # rank-major rows (the
             dist.all_gather_into_tensor(out, logits, group=self.group)                         # shape every backend takes)

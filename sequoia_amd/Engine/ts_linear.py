@@ -301,10 +301,13 @@ def assert_same_plans_across_ranks(*models, group=None):
 
 
 # Small draft models (hidden <= 1024, <= 48 rows: every level of the 68m / 160m drafts): the RMSNorm in front of qkv,
-# gate_up and lm_head is computed inside the projection (csrc/draft_fused.hip) and o_proj / down_proj write the residual
-# stream through the "+ residual" epilogue -- 14 launches per 2-layer forward instead of 19.  SEQUOIA_DRAFT_FUSED=0 keeps
-# the general tall-skinny sequence.
-SMALL_FUSED = os.environ.get("SEQUOIA_DRAFT_FUSED", "1") != "0"
+# gate_up and lm_head can be computed inside the projection (csrc/draft_fused.hip) and o_proj / down_proj can write the
+# residual stream through the "+ residual" epilogue -- 14 launches per 2-layer forward instead of 19.  Measured on MI355X
+# (profiles/r03_draft_fused_not_adopted.md): NOT faster -- every kernel of the unfused sequence already sits at the
+# ~4.7 us per-kernel floor of a dependent graph node, and a fused kernel's body is the SUM of the two latency chains it
+# replaces (norm 1 load + reduce, then weights + MFMA + merge), so 5 fewer launches buy back what the longer bodies cost
+# (34-row level: 96 vs 88 us).  Kept as an opt-in (SEQUOIA_DRAFT_FUSED=1), covered by tests/test_draft_fused_gpu.py.
+SMALL_FUSED = os.environ.get("SEQUOIA_DRAFT_FUSED", "0") == "1"
 SMALL_MAX_ROWS, SMALL_MAX_HIDDEN = 48, 1024
 
 

@@ -22,18 +22,19 @@ from .. import native
 
 
 class XgmiAllReduce:
-    def __init__(self, lib, rank, world, ws_ptrs, own, opened, max_elems, device, group):
+    def __init__(self, lib, rank, world, ws_ptrs, own, opened, max_elems, device, group, max_gather_elems=0):
         self.lib, self.rank, self.world = lib, rank, world
         self._own, self._opened = own, opened
-        self.max_elems = max_elems
+        self.max_elems, self.max_gather_elems = max_elems, max_gather_elems
         self.device, self.group = device, group
         self._table = (C.c_void_p * world)(*ws_ptrs)
         self.calls = 0
 
     # ---- setup ------------------------------------------------------------------------------------------------
     @staticmethod
-    def create(group=None, device="cuda:0", max_elems=144 * 8192, self_check=True):
-        """max_elems: the largest tensor (fp16 elements) the job will reduce -- [144 rows, hidden]."""
+    def create(group=None, device="cuda:0", max_elems=144 * 8192, self_check=True, max_gather_elems=0):
+        """max_elems: the largest tensor (fp16 elements) the job will reduce -- [144 rows, hidden]; max_gather_elems: the
+        largest gathered tensor -- [144 rows, vocabulary]."""
         if not (dist.is_available() and dist.is_initialized()) or not str(device).startswith("cuda"):
             return None
         world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -41,7 +42,7 @@ class XgmiAllReduce:
             return None
         lib = native.load()
         torch.cuda.set_device(device)
-        nbytes = int(lib.sq_ar_workspace_bytes(world, max_elems))
+        nbytes = int(lib.sq_ar_workspace_bytes(world, max_elems, max_gather_elems))
         own = C.c_void_p()
         ok = lib.sq_ar_alloc(C.byref(own), nbytes) == native.SQ_OK
         handle = (C.c_ubyte * 64)()
@@ -70,7 +71,8 @@ class XgmiAllReduce:
                 opened.append(p.value)
         flags = [None] * world
         dist.all_gather_object(flags, failed, group=group)
-        ar = XgmiAllReduce(lib, rank, world, ptrs if not failed else [own.value] * world, own, opened, max_elems, device, group)
+        ar = XgmiAllReduce(lib, rank, world, ptrs if not failed else [own.value] * world, own, opened, max_elems, device, group,
+                           max_gather_elems)
         if any(flags):
             ar.close()
             return _refuse(rank, "hipIpcOpenMemHandle failed on rank(s) " + str([r for r, f in enumerate(flags) if f]))
@@ -103,6 +105,18 @@ class XgmiAllReduce:
             if not torch.equal(lo, hi):
                 ok = False
                 break
+        if ok and self.max_gather_elems >= 8 * self.world:
+            v = max(8, (min(4000, self.max_gather_elems // (self.world * 5)) // 8) * 8)
+            for rows in (1, 5):
+                gen.manual_seed(777 + rows + 10 * self.rank)
+                sl = torch.randn(rows, v, generator=gen).to(torch.float16).to(self.device)
+                parts = [torch.empty_like(sl) for _ in range(self.world)]
+                dist.all_gather(parts, sl, group=self.group)
+                got = self.gather_cols(sl)
+                torch.cuda.synchronize(self.device)
+                if self.status() != 0 or not torch.equal(got, torch.cat(parts, dim=1)):
+                    ok = False
+                    break
         verdicts = [None] * self.world
         dist.all_gather_object(verdicts, ok, group=self.group)
         if not all(verdicts):
@@ -119,6 +133,21 @@ class XgmiAllReduce:
                                                    int(blocks), torch.cuda.current_stream().cuda_stream), "sq_allreduce_sum_f16")
         self.calls += 1
         return x
+
+    def gather_cols(self, slice_: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """[rows, v] per rank -> [rows, world v] on every rank (rank r's columns at [r v, (r + 1) v))."""
+        rows, v = slice_.shape
+        if out is None:
+            out = torch.empty((rows, self.world * v), dtype=slice_.dtype, device=slice_.device)
+        native.check(self.lib.sq_allgather_cols_f16(slice_.data_ptr(), out.data_ptr(), rows, v, self.rank, self.world, self._table,
+                                                    self.max_elems, self.max_gather_elems,
+                                                    torch.cuda.current_stream().cuda_stream), "sq_allgather_cols_f16")
+        self.calls += 1
+        return out
+
+    def fits_gather(self, slice_: torch.Tensor) -> bool:
+        return (slice_.dtype == torch.float16 and slice_.is_contiguous() and slice_.dim() == 2 and slice_.shape[1] % 8 == 0
+                and 0 < slice_.numel() * self.world <= self.max_gather_elems)
 
     def fits(self, x: torch.Tensor) -> bool:
         return x.dtype == torch.float16 and x.is_contiguous() and x.numel() % 8 == 0 and 0 < x.numel() <= self.max_elems

@@ -27,10 +27,11 @@
 #define AR_SPIN_LIMIT (1u << 22)          // x (poll + s_sleep) ~ a few seconds; SEQUOIA_AR_SPIN_LIMIT overrides (tests)
 
 // workspace layout (bytes): [header 4 KB: status, per-block epochs] [flags1][flags2][area A: W slots][area B: n elements]
+// [area C: the all-gather's [rows][W v] image]
 struct ArLayout {
-    size_t flags1, flags2, area_a, area_b, total, chunk_cap;
+    size_t flags1, flags2, area_a, area_b, area_c, total, chunk_cap;
 };
-__host__ __device__ static inline ArLayout ar_layout(int world, size_t max_elems) {
+__host__ __device__ static inline ArLayout ar_layout(int world, size_t max_elems, size_t gather_elems = 0) {
     ArLayout L;
     const size_t flag_bytes = (size_t)AR_MAX_WORLD * AR_MAX_BLOCKS * AR_FLAG_STRIDE * 4;
     const size_t chunk = ((max_elems + world - 1) / world + 7) / 8 * 8;          // elements per chunk, 16-byte multiple
@@ -39,7 +40,8 @@ __host__ __device__ static inline ArLayout ar_layout(int world, size_t max_elems
     L.flags2 = L.flags1 + flag_bytes;
     L.area_a = L.flags2 + flag_bytes;
     L.area_b = L.area_a + (size_t)world * chunk * 2;
-    L.total = L.area_b + (size_t)world * chunk * 2;
+    L.area_c = L.area_b + (size_t)world * chunk * 2;                 // the all-gather's image (its own area: see below)
+    L.total = L.area_c + ((gather_elems + 7) / 8 * 8) * 2;
     return L;
 }
 
@@ -154,9 +156,9 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const Ar
     if (tid == 0) epochs[b] = epoch;           // the next call (or graph replay) of this block uses epoch + 1
 }
 
-extern "C" size_t sq_ar_workspace_bytes(int world, size_t max_elems) {
+extern "C" size_t sq_ar_workspace_bytes(int world, size_t max_elems, size_t max_gather_elems) {
     if (world < 1 || world > AR_MAX_WORLD || max_elems == 0) return 0;
-    return ar_layout(world, max_elems).total;
+    return ar_layout(world, max_elems, max_gather_elems).total;
 }
 
 extern "C" int sq_ar_alloc(void** ptr, size_t bytes) {
@@ -221,5 +223,104 @@ extern "C" int sq_allreduce_sum_f16(void* data, size_t n, int rank, int world, v
     }
     P.spin_limit = spin_limit;
     hipLaunchKernelGGL(allreduce_two_shot_kernel, dim3(P.blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, P);
+    return sq_check_launch();
+}
+
+// ---- all-gather of the vocabulary-parallel logits ------------------------------------------------------------------------------
+// Rank r holds out[:, r v : (r + 1) v] of the [rows][W v] logits (column-parallel lm_head).  One exchange: every rank
+// stores its [rows][v] slice into every peer's area C at the FINAL layout position (row i, columns r v ..), raises a
+// per-(peer, block) "written" flag, waits for its peers' flags and copies the foreign column blocks from its own area C
+// into the caller's tensor; then it raises a "read" flag -- the next all-gather waits for it before it overwrites that
+// peer's image (area C is the all-gather's own, so the all-reduces in between never touch it).  Rows are cut over the blocks.
+struct AgParams {
+    const half_t* slice;             // [rows][v] local
+    half_t* out;                     // [rows][W v] local
+    char* ws[AR_MAX_WORLD];
+    size_t max_elems, gather_elems;
+    int rows, v, rank, world, blocks;
+    uint32_t spin_limit;
+};
+
+__global__ void __launch_bounds__(AR_THREADS) allgather_cols_kernel(const AgParams P) {
+    const int b = blockIdx.x, tid = threadIdx.x, W = P.world, R = P.rank;
+    const ArLayout L = ar_layout(W, P.max_elems, P.gather_elems);
+    char* mine = P.ws[R];
+    uint32_t* status = (uint32_t*)mine;
+    uint32_t* epochs = (uint32_t*)(mine + 512);               // [blocks] (the all-reduce keeps its own at + 256)
+    __shared__ uint32_t s_epoch;
+    if (tid == 0) s_epoch = epochs[b] + 1;
+    __syncthreads();
+    const uint32_t epoch = s_epoch;
+    const int r0 = (int)((long)P.rows * b / P.blocks), r1 = (int)((long)P.rows * (b + 1) / P.blocks);
+    const int vec = P.v / 8;                                  // 16-byte vectors per slice row
+    const size_t ld = (size_t)W * P.v;
+    // the peers have read the previous image out of their area C (word + 12 of the flag line = "read" epoch)
+    if (tid < W && tid != R) {
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 12, epoch - 1, P.spin_limit))
+            atomicOr(status, 8u);
+    }
+    __syncthreads();
+    // my slice -> my own output and every peer's area C (final layout)
+    for (int i = r0; i < r1; ++i) {
+        for (int c = tid; c < vec; c += AR_THREADS) {
+            const half8 x = *(const half8*)(P.slice + (size_t)i * P.v + c * 8);
+            const size_t off = (size_t)i * ld + (size_t)R * P.v + c * 8;
+            *(half8*)(P.out + off) = x;
+            for (int d = 1; d < W; ++d) {
+                const int p = (R + d) % W;
+                *(half8*)((half_t*)(P.ws[p] + L.area_c) + off) = x;
+            }
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < W && tid != R)
+        ar_flag_store((uint32_t*)(P.ws[tid] + L.flags2) + ((size_t)R * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 8, epoch);
+    if (tid < W && tid != R) {
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 8, epoch, P.spin_limit))
+            atomicOr(status, 4u);
+    }
+    __syncthreads();
+    const half_t* img = (const half_t*)(mine + L.area_c);
+    for (int i = r0; i < r1; ++i) {
+        for (int d = 1; d < W; ++d) {
+            const int p = (R + d) % W;
+            for (int c = tid; c < vec; c += AR_THREADS) {
+                const size_t off = (size_t)i * ld + (size_t)p * P.v + c * 8;
+                *(half8*)(P.out + off) = __builtin_nontemporal_load((const half8*)(img + off));
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < W && tid != R)          // "read": peer tid may overwrite block b's rows of my image in its next all-gather
+        ar_flag_store((uint32_t*)(P.ws[tid] + L.flags2) + ((size_t)R * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 12, epoch);
+    if (tid == 0) epochs[b] = epoch;
+}
+
+extern "C" int sq_allgather_cols_f16(const void* slice, void* out, int rows, int v, int rank, int world, void* const* ws,
+                                     size_t max_elems, size_t max_gather_elems, void* stream) {
+    if (!slice || !out || !ws || rows <= 0 || v <= 0 || world < 1 || world > AR_MAX_WORLD || rank < 0 || rank >= world) return SQ_EINVAL;
+    if ((v & 7) || ((uintptr_t)slice & 15) || ((uintptr_t)out & 15) || (size_t)rows * world * v > max_gather_elems)
+        return SQ_EUNSUPPORTED;
+    AgParams P;
+    P.slice = (const half_t*)slice; P.out = (half_t*)out; P.rows = rows; P.v = v; P.rank = rank; P.world = world;
+    P.max_elems = max_elems; P.gather_elems = max_gather_elems;
+    for (int i = 0; i < AR_MAX_WORLD; ++i) P.ws[i] = i < world ? (char*)ws[i] : nullptr;
+    for (int i = 0; i < world; ++i)
+        if (!P.ws[i]) return SQ_EINVAL;
+    if (world == 1) {
+        if (slice != out && hipMemcpyAsync(out, slice, (size_t)rows * v * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return SQ_ELAUNCH;
+        return SQ_OK;
+    }
+    P.blocks = rows < AR_MAX_BLOCKS ? rows : AR_MAX_BLOCKS;
+    static uint32_t spin_limit = 0;
+    if (!spin_limit) {
+        const char* e = getenv("SEQUOIA_AR_SPIN_LIMIT");
+        const long vv = e ? atol(e) : 0;
+        spin_limit = vv > 0 ? (uint32_t)vv : AR_SPIN_LIMIT;
+    }
+    P.spin_limit = spin_limit;
+    hipLaunchKernelGGL(allgather_cols_kernel, dim3(P.blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, P);
     return sq_check_launch();
 }

@@ -39,6 +39,75 @@ struct DnParams {
     float eps;
 };
 
+// Prologue of dn_linear_kernel: KPW k-steps per wave (k = 128 KPW), MT row tiles.  Lane (r = lane % 16, cg = lane / 16)
+// of wave w holds, for every row tile, the chunks 4 i + cg of the k-steps i = w, w + 4, ... of row 16 mt + r.
+template <int MT, int KPW>
+__device__ __forceinline__ void dn_prologue(const DnParams& P, half_t* a_lds, float* ss_lds, int wave, int lane) {
+    const int r16 = lane & 15, g4 = lane >> 4;
+    half8 v[MT][KPW];
+    const half_t* src[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = min(mt * 16 + r16, P.m - 1);             // rows beyond m re-read the last row; zeroed below
+        if (P.ids) {
+            int64_t id = P.ids[row];
+            id = id < 0 ? 0 : (id >= P.vocab ? P.vocab - 1 : id);
+            src[mt] = P.embed + (size_t)id * P.k;
+        } else {
+            src[mt] = P.x + (size_t)row * P.k;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) v[mt][j] = *(const half8*)(src[mt] + (((j * DN_WAVES + wave) * 4 + g4) * 8));
+    half8 gw[KPW];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) gw[j] = *(const half8*)(P.g + (((j * DN_WAVES + wave) * 4 + g4) * 8));
+    // sum of squares: this lane's chunks, the row's 4 lanes, then the 4 waves through LDS (fixed order)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < KPW; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += (float)v[mt][j][e] * (float)v[mt][j][e];
+        const float s1 = ss + __shfl_xor(ss, 16, 64);
+        const float s2 = s1 + __shfl_xor(s1, 32, 64);
+        if (g4 == 0) ss_lds[wave * (DN_MAX_MT * 16) + mt * 16 + r16] = s2;
+    }
+    if (P.ids && P.x_out && blockIdx.x == 0) {                   // first layer: workgroup 0 also writes the residual stream
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = mt * 16 + r16;
+            if (row < P.m) {
+#pragma unroll
+                for (int j = 0; j < KPW; ++j)
+                    *(half8*)(P.x_out + (size_t)row * P.k + (((j * DN_WAVES + wave) * 4 + g4) * 8)) = v[mt][j];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float* q = ss_lds + mt * 16 + r16;
+        const float tot = ((q[0] + q[DN_MAX_MT * 16]) + q[2 * DN_MAX_MT * 16]) + q[3 * DN_MAX_MT * 16];
+        const float inv = rsqrtf(tot / (float)P.k + P.eps);
+        const bool live = mt * 16 + r16 < P.m;
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const half_t n = (half_t)((float)v[mt][j][e] * inv);
+                o[e] = (half_t)((float)gw[j][e] * (float)n);
+            }
+            if (!live) o = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            *(half8*)(a_lds + (((size_t)(j * DN_WAVES + wave) * MT + mt) * 64 + lane) * 8) = o;
+        }
+    }
+}
+
 template <int MT, int NT, bool SWIGLU>
 __global__ void __launch_bounds__(DN_THREADS) dn_linear_kernel(const DnParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dn_lds[];
@@ -51,61 +120,7 @@ __global__ void __launch_bounds__(DN_THREADS) dn_linear_kernel(const DnParams P)
     const int r16 = lane & 15, g4 = lane >> 4;
     const int ksteps = P.k >> 5;
 
-    // ---- prologue: normalise the activation block into LDS (waves 0 .. mtp-1: one 16-row tile each) ----------------
-    if (wave < P.mtp) {
-        const int row = wave * 16 + r16;
-        const bool live = row < P.m;
-        const half_t* src = nullptr;
-        if (live) {
-            if (P.ids) {
-                int64_t id = P.ids[row];
-                id = id < 0 ? 0 : (id >= P.vocab ? P.vocab - 1 : id);
-                src = P.embed + (size_t)id * P.k;
-            } else {
-                src = P.x + (size_t)row * P.k;
-            }
-        }
-        half8 v[DN_MAX_K / 32];
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < DN_MAX_K / 32; ++i) {
-            if (i < ksteps) {
-                v[i] = live ? *(const half8*)(src + (i * 4 + g4) * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < DN_MAX_K / 32; ++i) {
-            if (i < ksteps) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ss += (float)v[i][j] * (float)v[i][j];
-            }
-        }
-        // the row's 4 lanes (r, r + 16, r + 32, r + 48): fixed order
-        const float s1 = ss + __shfl_xor(ss, 16, 64);
-        const float tot = s1 + __shfl_xor(s1, 32, 64);
-        const float inv = rsqrtf(tot / (float)P.k + P.eps);
-        if (P.ids && P.x_out && blockIdx.x == 0 && live) {
-#pragma unroll
-            for (int i = 0; i < DN_MAX_K / 32; ++i)
-                if (i < ksteps) *(half8*)(P.x_out + (size_t)row * P.k + (i * 4 + g4) * 8) = v[i];
-        }
-#pragma unroll
-        for (int i = 0; i < DN_MAX_K / 32; ++i) {
-            if (i < ksteps) {
-                const half8 gw = *(const half8*)(P.g + (i * 4 + g4) * 8);
-                half8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const half_t n = (half_t)((float)v[i][j] * inv);
-                    o[j] = live ? (half_t)((float)gw[j] * (float)n) : (half_t)0;
-                }
-                *(half8*)(a_lds + (((size_t)i * MT + wave) * 64 + lane) * 8) = o;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- this workgroup's column units, this wave's K range ------------------------------------------------------------
+    // ---- this workgroup's column units, this wave's K range; the first weight loads go out BEFORE the prologue (they do not depend on it) ------------------------------------------------------------
     const int tile = blockIdx.x;
     const int u0 = (int)((long)tile * P.units / P.tiles), u1 = (int)((long)(tile + 1) * P.units / P.tiles);
     const int nu = u1 - u0;
@@ -126,12 +141,11 @@ __global__ void __launch_bounds__(DN_THREADS) dn_linear_kernel(const DnParams P)
         for (int t = 0; t < NT; ++t) acc[mt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int D = NT <= 2 ? 6 : (NT <= 4 ? 4 : 2);       // k-steps of weight loads in flight per wave
-    if (ks0 < ks1) {
-        half8 wr[D][NT];
-        const int nst = ks1 - ks0;
+    half8 wr[D][NT];
+    const int nst = ks1 - ks0;
 #define DN_LOAD(d, I)                                                                                          \
     {                                                                                                          \
-        const uint32_t kw_ = (uint32_t)(ks0 + min((I), nst - 1)) << 10;                                        \
+        const uint32_t kw_ = (uint32_t)(ks0 + max(0, min((I), nst - 1))) << 10;                                \
         _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                         \
             wr[d][t] = __builtin_nontemporal_load((const half8*)(wbase + (woff[t] + kw_)));                    \
     }
@@ -145,7 +159,20 @@ __global__ void __launch_bounds__(DN_THREADS) dn_linear_kernel(const DnParams P)
         }                                                                                                      \
     }
 #pragma unroll
-        for (int d = 0; d < D; ++d) DN_LOAD(d, d);
+    for (int d = 0; d < D; ++d) DN_LOAD(d, d);               // (an empty K range re-reads k-step ks0 - harmless, never used)
+
+    // ---- prologue: normalise the activation block into LDS; all 4 waves, wave w takes k-steps w, w + 4, ... ----------------
+    // (straight-line per K: a predicate around the loads would make the compiler drain vmcnt at every join)
+    float* ss_lds = (float*)(dn_lds + 160 * 1024 - DN_WAVES * DN_MAX_MT * 16 * sizeof(float));     // [wave][MT * 16]
+    switch (ksteps >> 2) {
+        case 2: dn_prologue<MT, 2>(P, a_lds, ss_lds, wave, lane); break;
+        case 4: dn_prologue<MT, 4>(P, a_lds, ss_lds, wave, lane); break;
+        case 6: dn_prologue<MT, 6>(P, a_lds, ss_lds, wave, lane); break;
+        default: dn_prologue<MT, 8>(P, a_lds, ss_lds, wave, lane); break;
+    }
+    __syncthreads();
+
+    if (ks0 < ks1) {
         const int nfull = nst / D, rem = nst - nfull * D;
         int i = 0;
         for (int it = 0; it < nfull; ++it, i += D) {
@@ -211,9 +238,10 @@ __global__ void __launch_bounds__(DN_THREADS) dn_linear_kernel(const DnParams P)
 }
 
 static size_t dn_lds_bytes(int mt, int nt, int k) {
-    const size_t a = (size_t)(k / 32) * mt * 64 * 8 * sizeof(half_t);
-    const size_t mg = (size_t)DN_WAVES * mt * 16 * (nt * 16 + 4) * sizeof(float);
-    return a > mg ? a : mg;
+    // the prologue's cross-wave sums sit at the END of the 160 KB window (fixed address: the kernel does not need the
+    // size), so the launch always asks for the whole window; the activation image / the merge tiles start at 0
+    (void)mt; (void)nt; (void)k;
+    return 160 * 1024;
 }
 
 template <int MT, int NT, bool SWIGLU>
@@ -252,7 +280,7 @@ extern "C" int sq_norm_linear_f16(const void* x, const int64_t* d_ids, const voi
     if (!norm_weight || !w_frag || !out || m <= 0 || n_out <= 0 || k <= 0 || tiles < 1) return SQ_EINVAL;
     if (!d_ids && !x) return SQ_EINVAL;
     if (d_ids && (!embed || vocab <= 0)) return SQ_EINVAL;
-    if (m > DN_MAX_MT * 16 || k > DN_MAX_K || (k & 31) || (n_out & 15) || (swiglu && (n_out & 31)) || (!swiglu && (ldo < n_out || (ldo & 7))) ||
+    if (m > DN_MAX_MT * 16 || k > DN_MAX_K || (k & 255) || (n_out & 15) || (swiglu && (n_out & 31)) || (!swiglu && (ldo < n_out || (ldo & 7))) ||
         ((uintptr_t)w_frag & 15) || ((uintptr_t)out & 15) || (x && ((uintptr_t)x & 15)) || ((uintptr_t)norm_weight & 15) ||
         (size_t)(swiglu ? 2 : 1) * n_out * k * 2 >= (1ull << 32))
         return SQ_EUNSUPPORTED;

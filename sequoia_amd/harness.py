@@ -32,15 +32,19 @@ MODELS = {
 }
 
 
-def tp_capturable() -> bool:
-    """Can the tensor-parallel forward be captured into a hipGraph?  Yes with RCCL (backend "nccl") or without a process
-    group; not with gloo (its collectives run through the host).  SEQUOIA_TP_GRAPHS=0 forces eager forwards."""
+def tp_capturable(target=None) -> bool:
+    """Can the tensor-parallel forward be captured into a hipGraph?  Yes with RCCL (backend "nccl"), without a process
+    group, or when the engine runs both collectives on the xGMI kernels (no torch.distributed call in a tree forward);
+    not when a gloo collective (through the host) is on the path.  SEQUOIA_TP_GRAPHS=0 forces eager forwards."""
     if os.environ.get("SEQUOIA_TP_GRAPHS", "1") == "0":
         return False
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return True
-    return dist.get_backend() == "nccl"
+    if dist.get_backend() == "nccl":
+        return True
+    inner = getattr(target, "engine", None)
+    return bool(getattr(inner, "collectives_capturable", False))
 
 
 def load_prompts():
@@ -98,7 +102,7 @@ class Loop:
             draft.initialize_cuda_graph(lens, tree_bitmask=gdev["bitmask"], n_tree=g.size)
             # (tensor-parallel target: the verify forward is captured WITH its collectives -- the xGMI all-reduce kernel
             # and RCCL calls are stream-ordered and legal inside a capture; a gloo group is not: eager then)
-            if hasattr(target, "initialize_cuda_graph") and (not cfg.get("tp") or tp_capturable()):
+            if hasattr(target, "initialize_cuda_graph") and (not cfg.get("tp") or tp_capturable(target)):
                 target.initialize_cuda_graph([g.size], tree_bitmask=gdev["bitmask"], n_tree=g.size)
         self.pi = 0
         self.tree = None
@@ -107,7 +111,7 @@ class Loop:
         # device-driven steps under tensor parallelism too: the step block, the result ring and the decisions are per
         # rank and identical on every rank (replicated draft / sampler / verifier, same noise), so every rank replays
         # the same whole-step graph -- collectives included -- without any broadcast
-        self.pipelined = bool(pipelined) and str(device).startswith("cuda") and (not cfg.get("tp") or tp_capturable())
+        self.pipelined = bool(pipelined) and str(device).startswith("cuda") and (not cfg.get("tp") or tp_capturable(target))
 
     def _new_prompt(self):
         self.draft.clear_kv(); self.target.clear_kv()

@@ -69,7 +69,7 @@ PROTOTYPES = {
     "sq_add_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_silu_mul_frag_f16": (_i, [_vp, _vp, _i, _i, _vp]),
     "sq_norm_linear_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "sq_ar_workspace_bytes": (C.c_size_t, [_i, C.c_size_t]),
+    "sq_ar_workspace_bytes": (C.c_size_t, [_i, C.c_size_t, C.c_size_t]),
     "sq_ar_alloc": (_i, [C.POINTER(_vp), C.c_size_t]),
     "sq_ar_free": (_i, [_vp]),
     "sq_ar_ipc_export": (_i, [_vp, _vp]),
@@ -77,6 +77,7 @@ PROTOTYPES = {
     "sq_ar_ipc_close": (_i, [_vp]),
     "sq_ar_status": (_i, [_vp, C.POINTER(_i)]),
     "sq_allreduce_sum_f16": (_i, [_vp, C.c_size_t, _i, _i, C.POINTER(_vp), C.c_size_t, _i, _vp]),
+    "sq_allgather_cols_f16": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(_vp), C.c_size_t, C.c_size_t, _vp]),
 }
 
 _lib = None

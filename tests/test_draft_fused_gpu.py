@@ -1,8 +1,8 @@
 """Small-draft fusion (csrc/draft_fused.hip, Engine/ts_linear.py::forward_small_fused): the RMSNorm computed inside the
 projection that consumes it, the residual stream written by the o_proj / down_proj epilogue.  Kernel level against the
 numpy oracle's rmsnorm + linear (the reference's rounding points), forward level against the unfused tall-skinny sequence
-and the general (hipBLASLt + glue) path on the 68m architecture; the end-to-end traces (tests/test_e2e_gpu.py) run their
-draft levels through it by default."""
+and the general (hipBLASLt + glue) path on the 68m architecture.  The path is an opt-in (SEQUOIA_DRAFT_FUSED=1): measured
+no faster than the unfused sequence (profiles/r03_draft_fused_not_adopted.md)."""
 import numpy as np
 import pytest
 import torch
@@ -105,7 +105,7 @@ def test_norm_linear_swiglu_matches_unfused_kernels(hip, m):
         assert not pad.any()
 
 
-def test_fused_draft_forward_matches_unfused_and_general_path():
+def test_fused_draft_forward_matches_unfused_and_general_path(monkeypatch):
     """68m architecture, a 34-token tree level after a 126-token prefill: the fused sequence, the tall-skinny sequence and
     the general path give the same logits up to accumulation order, and the same KV rows."""
     from sequoia_amd.Engine import ts_linear
@@ -121,6 +121,7 @@ def test_fused_draft_forward_matches_unfused_and_general_path():
     ids = torch.randint(3, 32000, (1, 161), device=DEV)
     model = eng.engine.model
     ts = model.ts
+    monkeypatch.setattr(ts_linear, "SMALL_FUSED", True)       # opt-in path (SEQUOIA_DRAFT_FUSED=1)
     assert ts is not None and ts_linear.small_fused_ok(model, ts, 34)
     outs, caches = {}, {}
     pos = torch.arange(161, device=DEV)
@@ -136,18 +137,19 @@ def test_fused_draft_forward_matches_unfused_and_general_path():
                             attn_mask=None, tree=TreeContext(160, 161, g.size, bm, 161))
         outs[mode] = (lv.float().clone(), one.float().clone())
         caches[mode] = (eng.engine.kv_cache.k_cache[:, :, :, :161].float().clone(), eng.engine.kv_cache.v_cache[:, :, :, :161].float().clone())
-    ts_linear.SMALL_FUSED = True
     model.ts = ts
     for other in ("ts", "general"):
         for a, b in zip(outs["fused"], outs[other]):
-            assert (a - b).abs().max() < 6e-2, (other, float((a - b).abs().max()))       # logits of magnitude ~10
+            assert (a - b).abs().max() < (6e-2 if other == "ts" else 1e-1), (other, float((a - b).abs().max()))   # logits of magnitude ~10-16: a few fp16 ulps
             assert (a.argmax(-1) == b.argmax(-1)).float().mean() > 0.9
         for a, b in zip(caches["fused"], caches[other]):
             assert (a - b).abs().max() < 2e-2
 
 
-def test_fused_draft_forward_replays_from_a_graph():
+def test_fused_draft_forward_replays_from_a_graph(monkeypatch):
+    from sequoia_amd.Engine import ts_linear
     from sequoia_amd.Engine.Engine import GraphInferenceEngine
+    monkeypatch.setattr(ts_linear, "SMALL_FUSED", True)
     from sequoia_amd.Engine.Llama_modules import TreeContext
     from sequoia_amd.growmap import GrowMap
     M = 384

@@ -28,7 +28,7 @@ def _ar_worker(rank, world, port, out_dir):
     dev = "cuda:0"
     torch.cuda.set_device(0)
     from sequoia_amd.Engine.xgmi_allreduce import XgmiAllReduce
-    ar = XgmiAllReduce.create(None, dev, max_elems=144 * 8192)
+    ar = XgmiAllReduce.create(None, dev, max_elems=144 * 8192, max_gather_elems=144 * 32000)
     assert ar is not None, "xGMI all-reduce could not be set up on this box (see stderr)"
     res = dict(sizes=[], graph=False, burst=False)
     gen = torch.Generator(device="cpu")
@@ -50,6 +50,21 @@ def _ar_worker(rank, world, port, out_dir):
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), f"n = {n}: ranks hold different bits"
         res["sizes"].append(n)
+    # 1b. all-gather of column-parallel logits: [rows, v] per rank -> [rows, W v], exact, interleaved with all-reduces
+    for i, (rows, v) in enumerate([(1, 16000), (129, 16000), (34, 8), (144, 16000)]):
+        gen.manual_seed(400 + 3 * i + rank)
+        sl = torch.randn(rows, v, generator=gen).half().to(dev)
+        parts = [torch.empty_like(sl) for _ in range(world)]
+        dist.all_gather(parts, sl)
+        y = torch.ones(129 * 8192, dtype=torch.float16, device=dev)
+        ar(y)                                                   # an all-reduce right before and right after
+        got = ar.gather_cols(sl)
+        ar(y)
+        got2 = ar.gather_cols(sl)                               # back to back: the "read" handshake
+        torch.cuda.synchronize()
+        assert ar.status() == 0
+        assert torch.equal(got, torch.cat(parts, dim=1)) and torch.equal(got2, got), f"gather {rows} x {v}"
+        assert float(y[0]) == world * world
     # 2. a burst of back-to-back calls without host synchronisation, arrival skewed (one rank is kept busy / asleep):
     #    call k + 1 of the fast rank must not disturb call k of the slow one (per-block epochs, areas reused every call)
     n = 129 * 8192
@@ -156,3 +171,59 @@ def test_tp2_on_the_xgmi_allreduce_matches_reference_trace(name, tmp_path, monke
     for r in range(2):
         matched, diverged = np.load(tmp_path / f"r{r}.npy")
         assert diverged == -1 and matched == 2, f"rank {r}: {matched} steps, diverged at {diverged}"
+
+
+def _tp_pipe_worker(rank, world, port, name, out_dir):
+    """Two tensor-parallel ranks on cuda:0 (gloo for the setup only): the whole speculation step -- replicated draft,
+    sharded target with BOTH collectives on the xGMI kernels, verifier, compactions -- captured as one hipGraph per rank
+    and driven by the device; must commit the synchronous run's tokens on both ranks."""
+    sys.path.insert(0, REPO); sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SEQUOIA_TP_REQUIRE_XGMI"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    from conftest import load_trace
+    from helpers import dims_dict, make_tree, pipelined_run, state_dict_of, sync_run
+    from sequoia_amd.Engine import ts_linear
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine
+    from sequoia_amd.Engine.offload_engine import OffloadEngine
+    from sequoia_amd.harness import tp_capturable
+    ts_linear.DETERMINISTIC_PLANS = True
+    z, meta = load_trace(name)
+    M = meta["M"]
+    dspec = dict(state_dict=state_dict_of(z, "draft"), config=dims_dict(meta["draft_dims"], meta["vocab"]))
+    tspec = dict(state_dict=state_dict_of(z, "target"), config=dims_dict(meta["target_dims"], meta["vocab"]))
+    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=dev)
+    target = OffloadEngine(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=dev)
+    assert target.engine.xgmi is not None and tp_capturable(target)
+    n_steps = int(z["n_steps"]) + 2
+    tree = make_tree(z, meta, draft, target, dev)
+    want = sync_run(tree, n_steps)
+    draft.clear_kv(); target.clear_kv()
+    tree = make_tree(z, meta, draft, target, dev, step_graph=True)
+    assert tree.state is not None and tree.state.graph is not None
+    got, _ = pipelined_run(tree, max_steps=len(want))
+    torch.cuda.synchronize()
+    assert target.engine.xgmi.status() == 0
+    assert [g[0] for g in got] == [w[0] for w in want], (got, [w[0] for w in want])
+    a_end = want[-1][0]
+    assert np.array_equal(tree.tokens[:a_end].cpu().numpy(), want[-1][1][:a_end])
+    mine = torch.tensor([g[0] for g in got])
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    assert all(torch.equal(b, mine) for b in both)
+    ts_linear.assert_same_plans_across_ranks(draft.engine.model, target.engine.model)
+    np.save(os.path.join(out_dir, f"tp{rank}.npy"), np.array([len(got), a_end]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["E_64x2", "A_2chain"])
+def test_tp2_whole_step_graph_device_driven_on_xgmi_collectives(name, tmp_path):
+    port = 37900 + (os.getpid() % 1500)
+    mp.spawn(_tp_pipe_worker, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
+    a = [np.load(tmp_path / f"tp{r}.npy") for r in range(2)]
+    assert np.array_equal(a[0], a[1]) and a[0][0] >= 3
