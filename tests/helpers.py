@@ -120,7 +120,15 @@ def replay_trace(name, device, max_steps=None):
     return out, tree, draft, target, z, meta
 
 
-def check_replay(steps, z, meta, logit_tol=4e-2):
+def depth_tolerance(meta, base=4e-2):
+    """Logit tolerance of a replay against the reference's CPU run: `base` (a few fp16 ulps at |logit| ~ 8) for the
+    2-12-layer trace models; every decoder layer adds two fp16 roundings of the residual stream, independent between the
+    two runs, so the tolerance grows with sqrt(layers) beyond that -- 32 layers (the Llama-2-7b-dims traces): 0.113."""
+    layers = meta["target_dims"][2]
+    return base if layers <= 12 else base * (layers / 4.0) ** 0.5
+
+
+def check_replay(steps, z, meta, logit_tol=None):
     """Compare a replay with the reference trace, step by step.
 
     Requirements (the parity statement of DESIGN.md §3):
@@ -133,6 +141,8 @@ def check_replay(steps, z, meta, logit_tol=4e-2):
         the comparison stops there (returned as `diverged_at`).
     Returns (n_matched_steps, diverged_at or None)."""
     import numpy as np
+    if logit_tol is None:
+        logit_tol = depth_tolerance(meta)
     succ = meta["successors"]
     n = len(succ)
     parent = {c: p for p, ch in enumerate(succ) for c in ch}
