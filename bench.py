@@ -208,10 +208,10 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
     ops_mod.set_ops_for_testing(OracleOps() if numpy_ops else TorchCpuOps())     # numpy_ops: the checking oracle (slow)
     # fp16 CPU GEMMs of <= 255 rows do not scale past a few dozen threads (128 threads: 13 s / step, 8 threads: 3.3 s on one
     # box, the other way round on another): after the prefill step ONE steady step is timed at each of 8 / 16 / 32
-    # threads (SEQUOIA_CPU_THREADS=a,b,c overrides) and the fastest is the baseline -- the honest best of this host
+    # threads and 64 (SEQUOIA_CPU_THREADS=a,b,c overrides) and the fastest is the baseline -- the honest best of this host
     prev_threads = torch.get_num_threads()
     avail = os.cpu_count() or prev_threads
-    sweep = [int(x) for x in os.environ.get("SEQUOIA_CPU_THREADS", "8,16,32").split(",") if x.strip()]
+    sweep = [int(x) for x in os.environ.get("SEQUOIA_CPU_THREADS", "8,16,32,64").split(",") if x.strip()]
     sweep = sorted({max(1, min(t, avail)) for t in sweep}) or [prev_threads]
     torch.set_num_threads(sweep[len(sweep) // 2])
     try:
@@ -303,7 +303,7 @@ def allreduce_timing(target, device, rows, reps=40):
     if getattr(inner, "xgmi", None) is not None:
         out["xgmi_us"] = timeit(lambda: inner.xgmi(x))
         out["xgmi_status"] = inner.xgmi.status()
-    out["rccl_us"] = timeit(lambda: dist.all_reduce(x))
+    out[("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) + "_us"] = timeit(lambda: dist.all_reduce(x))
     return out
 
 
