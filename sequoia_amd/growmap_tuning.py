@@ -13,6 +13,13 @@ which child the verifier's result record names, (2) and (3) time construct_grow_
 speculation steps on a representative growmap of each budget.  The result feeds sequoia_amd.tree_search.
 
     python -m sequoia_amd.growmap_tuning --config B --out gpurun_out/MI355X-68m-7b-stochastic.json
+
+Configuration E (70B target tensor-parallel over N GPUs; the reference's analogue is Engine/offloading_profile.py:1-48 + its
+missing `L40-*-7b-70b-*` growmaps) runs under the launcher, one rank per GPU; every rank measures (the forwards are
+collective), rank 0 writes the growmap in the reference's format (tree_search.py:121-128):
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m sequoia_amd.growmap_tuning \
+        --config E --out growmaps/MI355X-TP8-7b-70b-stochastic.json
 """
 from __future__ import annotations
 
@@ -104,14 +111,33 @@ def measure_step_times(cfg, draft, target, device, prompts, budgets, p_vec, max_
 
 def tune(config_name: str = "B", pair: str = "calibrated", device: str = "cuda:0", width: int = 32,
          accept_steps: int = 400, budgets=(2, 4, 8, 16, 32, 48, 64, 96, 128), max_depth: int = 10,
-         time_steps: int = 16):
+         time_steps: int = 16, static_rows: int = 0):
+    """static_rows > 0: the acceptance vector comes from the teacher-forced estimator (acceptance_static.py, the
+    reference's tests/fast_test.py) over that many 256-token rows instead of star-tree speculation steps."""
+    import os
     cfg = dict(MODELS[config_name])
-    from . import gemm_tuning
-    gemm_tuning.enable(tune_missing=False)          # shipped winners for the 128-row shapes, defaults elsewhere
+    tp = bool(cfg.get("tp")) and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if not tp:
+        from . import gemm_tuning
+        gemm_tuning.enable(tune_missing=False)      # shipped winners for the 128-row shapes, defaults elsewhere
+        # (tensor-parallel ranks must run identical arithmetic: no per-rank GEMM tuning there)
+    if tp:
+        torch.manual_seed(17)                       # identical noise on every rank: replicated decisions
     draft, target, _ = build(cfg, device, pair)
     prompts = load_prompts()
     with torch.inference_mode():
-        p_vec = measure_acceptance_vector(cfg, draft, target, device, prompts, width, accept_steps)
+        if static_rows > 0:
+            from .acceptance_static import static_acceptance_vector
+            # (the bundled c4_small rows hold 128 tokens: positions 64..127 are evaluated; the reference evaluates
+            # positions 128..255 of 256-token rows, tests/fast_test.py:63)
+            rows = [p[:256] for p in prompts[:static_rows]]
+            a = static_acceptance_vector(draft, target, rows, k=width, T=0.6, top_p=1.0, draft_top_p=1.1,
+                                         start=min(128, min(len(r) for r in rows) // 2), device=device)
+            p_vec = np.zeros(width + 2, dtype=np.float32)
+            p_vec[:width + 1] = a.numpy()
+            p_vec[width + 1] = max(0.0, 1.0 - float(a.sum()))
+        else:
+            p_vec = measure_acceptance_vector(cfg, draft, target, device, prompts, width, accept_steps)
         draft.clear_kv(); target.clear_kv()
         t_ar = measure_autoregressive_time(cfg, target, device, prompts)
         d_time, t_time, detail = measure_step_times(cfg, draft, target, device, prompts, list(budgets), p_vec,
@@ -137,9 +163,30 @@ def main(argv=None):
     ap.add_argument("--max-depth", type=int, default=10)
     ap.add_argument("--budgets", type=int, nargs="+", default=[2, 4, 8, 16, 32, 48, 64, 96, 128])
     ap.add_argument("--out", required=True, help="growmap destination (.json successors fixture or reference-format .pt)")
+    ap.add_argument("--static-rows", type=int, default=0,
+                    help="> 0: acceptance vector from the teacher-forced estimator (tests/fast_test.py) over this many rows")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     args = ap.parse_args(argv)
-    g, report = tune(args.config, args.pair, "cuda:0", args.width, args.accept_steps, tuple(args.budgets), args.max_depth,
-                     args.time_steps)
+    import os
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SEQUOIA_BENCH_ONE_DEVICE", "0") == "1":
+        local = 0                                   # test rig: every rank on GPU 0 (with --backend gloo)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group("gloo")
+    torch.cuda.set_device(local)
+    g, report = tune(args.config, args.pair, f"cuda:{local}", args.width, args.accept_steps, tuple(args.budgets), args.max_depth,
+                     args.time_steps, args.static_rows)
+    report["tp_world"] = world if MODELS[args.config].get("tp") else 1
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
     tree_search.save_growmap(g, args.out)
     with open(args.out.rsplit(".", 1)[0] + ".report.json", "w") as f:
         json.dump(report, f, indent=1)
