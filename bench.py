@@ -324,8 +324,18 @@ def spawn_ranks(n: int) -> int:
 
 def tp_extra(n: int, args) -> dict:
     """Configuration E beside the replica headline when several GPUs are available: the 70B target tensor-parallel over
-    the same N GPUs (RCCL all-reduce over xGMI), as a CHILD job with a timeout -- a stuck collective cannot take the
-    headline line with it.  Returns the child's JSON line (trimmed) or an error record."""
+    the same N GPUs (whole-step graphs, collectives on the xGMI kernels, RCCL as their fallback), as a CHILD job with a
+    timeout -- a stuck collective cannot take the headline line with it.  A failed or timed-out first attempt is retried
+    once on RCCL collectives only (SEQUOIA_TP_ALLREDUCE=rccl).  Returns the child's JSON line (trimmed) or an error record."""
+    first = _tp_child(n, args, {})
+    if "error" not in first:
+        return first
+    second = _tp_child(n, args, {"SEQUOIA_TP_ALLREDUCE": "rccl"})
+    second["first_attempt"] = dict(collectives="xgmi", **{k: first[k] for k in ("error", "stderr") if k in first})
+    return second
+
+
+def _tp_child(n: int, args, extra_env: dict) -> dict:
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--config", "E", "--steps", str(min(args.steps, 12)),
            "--warmup", "2", "--no-cpu-baseline", "--no-autoregressive", "--no-tuned-growmap", "--no-tp-extra",
@@ -335,6 +345,7 @@ def tp_extra(n: int, args) -> dict:
                         "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
                         "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
     env["SEQUOIA_TS_EXCLUSIVE"] = "1"          # one copy of the 70B shard per rank
+    env.update(extra_env)
     import signal
     from types import SimpleNamespace
     # own session: on a timeout the whole tree (launcher + ranks) is killed by process group, nothing keeps a GPU
@@ -355,10 +366,10 @@ def tp_extra(n: int, args) -> dict:
     d = json.loads(lines[-1])
     keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "mean_accepted_len", "rccl_ranks", "config",
             "roofline", "allreduce", "prefill_steps_in_timed_region")
-    out = {k: d[k] for k in keep if k in d}
+    res = {k: d[k] for k in keep if k in d}
     if "config" in d:
-        out["step_loop"] = d["config"].get("step_loop")
-    return out
+        res["step_loop"] = d["config"].get("step_loop")
+    return res
 
 
 def selftest(args, world, rank):

@@ -349,6 +349,12 @@ size_t sq_linear_ts_workspace_bytes(int m, int n_out, int splits);
 int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const void* res, void* out, int ldo, int out_frag, int m,
                      int n_out, int k, int silu, int tiles, int splits, void* slab, size_t slab_bytes, void* stream);
 
+/* Measurement aid (tools/prefetch_probe.py): touches, from `grid` workgroups, one dword of every 128-byte line that the
+ * workgroups of sq_linear_ts_f16(..., tiles, splits) load in their first `depth` k-steps, so that those lines sit in the
+ * XCD L2s when the projection starts.  Not used by the product path.                                               */
+int sq_linear_ts_prefetch(const void* w_frag, int n_out, int k, int silu, int tiles, int splits, int depth, int grid,
+                          void* sink, void* stream);
+
 /* Embedding lookup + the first RMSNorm of a forward in one pass (Engine/Llama_model.py:151 + the first layer's
  * input_layernorm, Engine/Llama_modules.py:282-288): x_out[r] = embed[ids[r]] (the residual stream, row-major),
  * out = RMSNorm(x_out) * weight, row-major or (out_frag) fragment-major.  ids: int64 [rows], clamped to [0, vocab).   */

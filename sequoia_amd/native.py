@@ -61,6 +61,7 @@ PROTOTYPES = {
     "sq_add_rmsnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_linear_ts_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "sq_linear_ts_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp]),
+    "sq_linear_ts_prefetch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sq_repack_linear_weight_f16": (_i, [_vp, _vp, _i, _i, _vp]),
     "sq_repack_rows_frag_f16": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "sq_add_rmsnorm_slabs_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

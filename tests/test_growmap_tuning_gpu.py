@@ -79,3 +79,48 @@ def test_autoregressive_loop_graph_replay_equals_eager():
             loop.ops.sample_wor = orig
         out.append(toks)
     assert out[0] == out[1] and len(out[0]) >= 1
+
+
+def test_static_acceptance_vector_on_native_forwards_matches_cpu_path():
+    """The teacher-forced estimator (tests/fast_test.py) on the native forwards: the logits of the HIP forwards agree with
+    the CPU engines' within fp16 tolerance, so with the draws pinned (CPU generator, logits moved to the host) the two
+    vectors are close; layout [0, a_1 .. a_k] and the search accepts it."""
+    from oracle.ops_adapter import OracleOps
+    from sequoia_amd import ops
+    from sequoia_amd.acceptance_static import acceptance_from_logits, static_acceptance_vector
+    from sequoia_amd.Engine.Llama_modules import TreeContext
+    draft, target, meta, _ = _engines()
+    torch.manual_seed(11)
+    rows = [torch.randint(3, meta["vocab"], (96,)).tolist() for _ in range(2)]
+    vec = static_acceptance_vector(draft, target, rows, k=5, T=meta["T"], top_p=1.0, draft_top_p=1.1, start=64, device=DEV)
+    assert vec.shape == (6,) and float(vec[0]) == 0.0 and 0.0 < float(vec[1]) <= 1.0 and float(vec.sum()) <= 1.0 + 1e-5
+    # same rows through the CPU engines (oracle ops), same CPU-generator draws on host copies of the logits
+    z, _ = load_trace("B_seq128")
+    cdraft, ctarget = build_engines(z, meta, "cpu")
+    one_d, one_c = torch.ones((1, 1), dtype=torch.int64, device=DEV), torch.ones((1, 1), dtype=torch.int64)
+
+    def logits(eng, ids, dev, one):
+        t = torch.tensor(ids, dtype=torch.long, device=dev)
+        pos = torch.arange(len(ids), device=dev)
+        eng.clear_kv()
+        return eng.inference(input_ids=t[None], storage_ids=pos, position_ids=pos[None], attn_mask=None,
+                             tree=TreeContext(0, len(ids), 1, one, len(ids))).float().cpu()
+    got, want = [], []
+    for hip_side in (True, False):
+        if not hip_side:
+            ops.set_ops_for_testing(OracleOps())
+        try:
+            torch.manual_seed(5)
+            tot, n = torch.zeros(5), 0
+            for r in rows:
+                tl = logits(target if hip_side else ctarget, r, DEV if hip_side else "cpu", one_d if hip_side else one_c)
+                dl = logits(draft if hip_side else cdraft, r, DEV if hip_side else "cpu", one_d if hip_side else one_c)
+                (got if hip_side else want).append((tl.clone(), dl.clone()))
+                tot, c = acceptance_from_logits(tl, dl, None, 5, meta["T"], 1.0, 1.1, start=64, acc=tot)
+                n += c
+            (got if hip_side else want).append(tot / n)
+        finally:
+            ops.set_ops_for_testing(None)
+    for (a, b), (c, d) in zip(got[:2], want[:2]):
+        assert (a - c).abs().max() < 4e-2 and (b - d).abs().max() < 4e-2
+    assert (got[2] - want[2]).abs().max() < 0.08          # 64 positions: a handful of draws may flip inside the logit tolerance
