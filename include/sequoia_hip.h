@@ -369,6 +369,12 @@ int sq_embed_rmsnorm_f16(const int64_t* d_ids, const void* embed, int vocab, con
 int sq_add_rmsnorm_slabs_f16(const void* slab, int splits, const void* residual, const void* weight, void* sum_out,
                              void* out, int out_frag, int rows, int hidden, float eps, void* stream);
 
+/* SwiGLU fed by a split-K gate|up projection (the layer run as a plain [2 inter] x k sq_linear_ts_f16 with splits > 1:
+ * shapes whose activation block outweighs the weights, e.g. tensor-parallel shards at 129 rows): slab = fp32
+ * [splits][rows][2 inter] partials (gate columns, then up columns); out = h(h(silu(h(sum gate))) * h(sum up))
+ * (Engine/Llama_modules.py:271), fragment-major when out_frag != 0 (inter % 32 == 0), else row-major [rows][inter].  */
+int sq_silu_mul_slabs_f16(const void* slab, int splits, void* out, int out_frag, int rows, int inter, void* stream);
+
 /* ---- e: tensor-parallel all-reduce over peer-mapped buffers (xGMI) ------------------------------------------
  * The 70B target replaces the reference's host offload (Engine/offload_engine.py:388-451) by tensor parallelism over
  * the GPUs of one node: the row-parallel projections (o_proj, down_proj: Engine/Llama_modules.py:138,256,271 on a

@@ -55,26 +55,33 @@ def plan_key(n_out: int, k: int, silu: bool, mtp: int) -> str:
     return f"{n_out}x{k}{'s' if silu else ''}@{mtp}"
 
 
-SPLITTABLE = ("qkv", "o", "down")   # projections whose consumer reads split-K slabs: RoPE + KV write (qkv), the residual
-#                                     add + RMSNorm (o, down)
+SPLITTABLE = ("qkv", "o", "down", "gate_up")   # projections whose consumer reads split-K slabs: RoPE + KV write (qkv), the
+#   residual add + RMSNorm (o, down), the SwiGLU pass (gate_up: run as a plain [2 inter] x k layer, sq_silu_mul_slabs_f16)
 MAX_SPLITS = 8
 
 
 def candidates(n_out: int, k: int, silu: bool, m: int, allow_split: bool = False):
-    """(tiles, splits) launch shapes worth timing for one projection."""
-    units = n_out // 16
-    max_u = 3 if silu else (6 if m > 64 else 4)
+    """(tiles, splits) launch shapes worth timing for one projection.  SwiGLU layers: splits == 1 is the fused epilogue
+    (tiles over the n_out gate+up units, <= 3 each); splits > 1 runs the layer as a plain [2 n_out] x k projection
+    (tiles over 2 n_out / 16 column units) followed by sq_silu_mul_slabs_f16."""
     ksteps = k // 32
     out = []
-    tiles_opts = {(units + u - 1) // u for u in range(1, max_u + 1)}
-    tiles_opts |= {t for t in (256, 512) if t <= units and (units + t - 1) // t <= max_u}
-    for tiles in sorted(tiles_opts):
-        for splits in (1, 2, 3, 4, 6, 8):
-            if splits > 1 and not allow_split:
-                continue
-            if ksteps < splits * 8 or not 48 <= tiles * splits <= 2100:
-                continue
-            out.append((tiles, splits))
+
+    def add(units, max_u, split_opts):
+        tiles_opts = {(units + u - 1) // u for u in range(1, max_u + 1)}
+        tiles_opts |= {t for t in (256, 512) if t <= units and (units + t - 1) // t <= max_u}
+        for tiles in sorted(tiles_opts):
+            for splits in split_opts:
+                if ksteps < splits * 8 or not 48 <= tiles * splits <= 2100:
+                    continue
+                out.append((tiles, splits))
+    wide = 6 if m > 64 else 4
+    if silu:
+        add(n_out // 16, 3, (1,))
+        if allow_split:
+            add(2 * n_out // 16, wide, (2, 3, 4))
+    else:
+        add(n_out // 16, wide, (1, 2, 3, 4, 6, 8) if allow_split else (1,))
     return out
 
 
@@ -102,8 +109,8 @@ class TsLinearSet:
         self.exclusive = False
         self._zero_rows = torch.zeros((MAX_ROWS, d.hidden_size), dtype=torch.float16, device=self.device)
         # split-K partials [splits][rows][n_out] fp32: one buffer for the model's life (captured graphs hold it)
-        self._slab = torch.empty(MAX_SPLITS * MAX_ROWS * max(self.shapes[n][0] for n in SPLITTABLE), dtype=torch.float32,
-                                 device=self.device)
+        self._slab = torch.empty(MAX_SPLITS * MAX_ROWS * max(self.shapes[n][0] * (2 if self.shapes[n][2] else 1) for n in SPLITTABLE),
+                                 dtype=torch.float32, device=self.device)
 
     @staticmethod
     def supported(weights, dims, reduce_fn=None) -> bool:
@@ -156,7 +163,7 @@ class TsLinearSet:
         max_u = 3 if silu else (6 if q_len > 64 else 4)
         tiles = max((units + max_u - 1) // max_u, min(units, 256))
         splits = 1
-        if name in SPLITTABLE:
+        if name in SPLITTABLE and not silu:       # (SwiGLU layers split K only by a measured plan)
             while tiles * splits < 192 and splits < MAX_SPLITS and (k // 32) >= (splits + 1) * 8:
                 splits += 1
         return (tiles, splits)
@@ -257,8 +264,12 @@ class TsLinearSet:
             slab = self._slab if splits > 1 else None
 
             def ts_fn(li, tiles=tiles, splits=splits, slab=slab):
-                ops.linear_ts(xf, self.frag(name, li), q_len, n_out, k, out=out, silu=silu, tiles=tiles, splits=splits,
-                              slab=slab)
+                if silu and splits > 1:          # plain [2 n_out] x k layer + the SwiGLU pass over its partials
+                    ops.linear_ts(xf, self.frag(name, li), q_len, 2 * n_out, k, tiles=tiles, splits=splits, slab=slab)
+                    ops.silu_mul_slabs(slab, splits, act, q_len, n_out)
+                else:
+                    ops.linear_ts(xf, self.frag(name, li), q_len, n_out, k, out=out, silu=silu, tiles=tiles, splits=splits,
+                                  slab=slab)
             for li in range(n_layers):                       # weight images exist before anything is captured
                 self.frag(name, li)
             t = timeit(ts_fn)
@@ -436,8 +447,12 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
         down_ts = plan["down"] is not None
         act = torch.empty(fs(q_len, inter) if down_ts else (q_len, inter), dtype=dt, device=dev)
         if plan["gate_up"] is not None:
-            tiles, _ = plan["gate_up"]
-            ops.linear_ts(h, ts.frag("gate_up", li), q_len, inter, hidden, out=act, silu=True, out_frag=down_ts, tiles=tiles)
+            tiles, gsplits = plan["gate_up"]
+            if gsplits > 1:      # shapes whose activation block outweighs the weights (TP shards): split K, SwiGLU from the slabs
+                ops.linear_ts(h, ts.frag("gate_up", li), q_len, 2 * inter, hidden, tiles=tiles, splits=gsplits, slab=slab)
+                ops.silu_mul_slabs(slab, gsplits, act, q_len, inter, out_frag=down_ts)
+            else:
+                ops.linear_ts(h, ts.frag("gate_up", li), q_len, inter, hidden, out=act, silu=True, out_frag=down_ts, tiles=tiles)
         else:
             gu = F.linear(h, lw.w_gate_up)
             if down_ts:

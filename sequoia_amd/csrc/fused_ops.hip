@@ -290,3 +290,41 @@ extern "C" int sq_silu_mul_frag_f16(const void* gate_up, void* out_frag, int row
                        (hipStream_t)stream, (const half_t*)gate_up, (half_t*)out_frag, inter, (rows + 15) / 16);
     return sq_check_launch();
 }
+
+// SwiGLU fed by a split-K gate|up projection: the projection ran as a plain [2 inter] x k layer with `splits` K-splits
+// (sq_linear_ts_f16, silu = 0) and left fp32 partials slab[s][rows][2 inter] (gate columns, then up columns); here
+// g = h(sum_s gate), u = h(sum_s up) -- the layer's fp16 output roundings, splits summed in order -- and
+// out = h(h(silu(g)) * u) (Engine/Llama_modules.py:271), written fragment-major (frag_mtp > 0) or row-major.
+__global__ void __launch_bounds__(ROW_THREADS)
+silu_mul_slabs_kernel(const float* __restrict__ slab, int splits, size_t split_stride, half_t* __restrict__ out, int inter,
+                      int frag_mtp) {
+    const size_t row = blockIdx.y;
+    const int c = blockIdx.x * ROW_THREADS + threadIdx.x;
+    if (c * 8 >= inter) return;
+    const float* gp = slab + row * 2 * inter + c * 8;
+    const float* up = gp + inter;
+    floatx4 g0 = *(const floatx4*)gp, g1 = *(const floatx4*)(gp + 4), u0 = *(const floatx4*)up, u1 = *(const floatx4*)(up + 4);
+    for (int s = 1; s < splits; ++s) {
+        g0 += *(const floatx4*)(gp + s * split_stride); g1 += *(const floatx4*)(gp + s * split_stride + 4);
+        u0 += *(const floatx4*)(up + s * split_stride); u1 += *(const floatx4*)(up + s * split_stride + 4);
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float gf = (float)(half_t)(j < 4 ? g0[j] : g1[j - 4]);
+        const half_t sg = (half_t)(gf / (1.0f + expf(-gf)));
+        o[j] = (half_t)((float)sg * (float)(half_t)(j < 4 ? u0[j] : u1[j - 4]));
+    }
+    *(half8*)(out + (frag_mtp ? frag_chunk_offset(row, c, frag_mtp) : row * inter + c * 8)) = o;
+}
+
+extern "C" int sq_silu_mul_slabs_f16(const void* slab, int splits, void* out, int out_frag, int rows, int inter, void* stream) {
+    if (!slab || !out || splits < 1 || rows < 0 || inter <= 0) return SQ_EINVAL;
+    if ((inter & 7) || (out_frag && (inter & 31)) || ((uintptr_t)slab & 15)) return SQ_EUNSUPPORTED;
+    if (rows == 0) return SQ_OK;
+    const int chunks = inter >> 3;
+    hipLaunchKernelGGL(silu_mul_slabs_kernel, dim3((chunks + ROW_THREADS - 1) / ROW_THREADS, rows), dim3(ROW_THREADS), 0,
+                       (hipStream_t)stream, (const float*)slab, splits, (size_t)rows * 2 * inter, (half_t*)out, inter,
+                       out_frag ? (rows + 15) / 16 : 0);
+    return sq_check_launch();
+}

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "sq_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_add_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_silu_mul_frag_f16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sq_silu_mul_slabs_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "sq_norm_linear_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sq_ar_workspace_bytes": (C.c_size_t, [_i, C.c_size_t, C.c_size_t]),
     "sq_ar_alloc": (_i, [C.POINTER(_vp), C.c_size_t]),

@@ -496,6 +496,14 @@ class HipOps:
               "sq_silu_mul_frag_f16")
         return out_frag
 
+    def silu_mul_slabs(self, slab, splits, out, rows, inter, out_frag=False):
+        """SwiGLU on the fp32 split-K partials [splits][rows][2 inter] of a gate|up projection."""
+        _need(slab, torch.float32, "slab"); _need(out, torch.float16, "out")
+        assert slab.numel() >= splits * rows * 2 * inter
+        check(self.lib.sq_silu_mul_slabs_f16(slab.data_ptr(), int(splits), out.data_ptr(), 1 if out_frag else 0, int(rows),
+                                             int(inter), self._stream()), "sq_silu_mul_slabs_f16")
+        return out
+
     def silu_mul(self, gate_up, out):
         _need(gate_up, torch.float16, "gate_up"); _need(out, torch.float16, "out")
         inter = out.shape[-1]

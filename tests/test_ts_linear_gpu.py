@@ -91,6 +91,30 @@ def test_linear_ts_swiglu_epilogue(m, inter, k, tiles, out_frag):
     assert (diff > 0).mean() < 2e-3 and diff.max() <= np.abs(ref.astype(np.float32)).max() * 2 ** -9
 
 
+@pytest.mark.parametrize("m,inter,k,tiles,splits,out_frag", [(129, 3584, 8192, 75, 3, True), (128, 1024, 1024, 43, 2, True),
+                                                             (34, 3072, 768, 96, 2, False), (144, 7168, 2048, 150, 4, True)])
+def test_split_k_gate_up_with_swiglu_from_slabs(m, inter, k, tiles, splits, out_frag):
+    """gate|up run as a plain [2 inter] x k projection with K-splits + sq_silu_mul_slabs_f16 == the fused SwiGLU epilogue
+    (exact operands: bit-equal up to the expf ulp of silu)."""
+    ops = _ops()
+    rng = np.random.default_rng(inter + m + splits)
+    a, w = _exact_operands(rng, m, 2 * inter, k)
+    af, wf = ops.repack_rows(_t(a)), ops.repack_weight(_t(w))
+    ref = O.linear_f16(a, w, silu=True)
+    slab = torch.empty(splits * m * 2 * inter, dtype=torch.float32, device=DEV)
+    ops.linear_ts(af, wf, m, 2 * inter, k, tiles=tiles, splits=splits, slab=slab)
+    out = torch.zeros(ops.frag_shape(m, inter) if out_frag else (m, inter), dtype=torch.float16, device=DEV)
+    ops.silu_mul_slabs(slab, splits, out, m, inter, out_frag=out_frag)
+    got = out.cpu().numpy()
+    if out_frag:
+        got = O.unfrag_rows(got, m, inter)
+    diff = np.abs(got.astype(np.float32) - ref.astype(np.float32))
+    assert (diff > 0).mean() < 2e-3 and diff.max() <= np.abs(ref.astype(np.float32)).max() * 2 ** -9
+    fused = torch.zeros_like(out)
+    ops.linear_ts(af, wf, m, inter, k, out=fused, silu=True, out_frag=out_frag, tiles=min(inter // 16, 256))
+    assert torch.equal(fused, out)          # same expf, same roundings: the two forms agree bit for bit on exact operands
+
+
 def test_linear_ts_random_operands_within_accumulation_tolerance():
     """Gaussian operands at the 7B o_proj shape: fp32 accumulation order is the only freedom (split-K, 4-wave
     partials), so results stay within a few fp32 ulps of a float64 reference before the fp16 rounding."""
@@ -236,11 +260,13 @@ def test_plan_candidates_respect_kernel_limits():
     from sequoia_amd.Engine.ts_linear import candidates
     for n_out, k, silu, m in [(12288, 4096, False, 128), (11008, 4096, True, 48), (11008, 4096, True, 128), (768, 3072, False, 34),
                               (32000, 768, False, 1)]:
-        units = n_out // 16
-        for tiles, splits in candidates(n_out, k, silu, m, allow_split=not silu):
+        for tiles, splits in candidates(n_out, k, silu, m, allow_split=True):
+            # a SwiGLU layer with K-splits runs as a plain [2 n_out] x k projection (+ sq_silu_mul_slabs_f16)
+            plain = not silu or splits > 1
+            units = (2 * n_out if silu and splits > 1 else n_out) // 16
             per = (units + tiles - 1) // tiles
-            assert per <= (3 if silu else (6 if m > 64 else 4))
-            assert k // 32 >= splits * 8 and (splits == 1 or not silu)
+            assert per <= ((6 if m > 64 else 4) if plain else 3)
+            assert k // 32 >= splits * 8
 
 
 def test_tensor_parallel_hooks_run_on_the_tall_skinny_path():

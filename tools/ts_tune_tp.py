@@ -23,6 +23,7 @@ ap.add_argument("--layers", type=int, default=6, help="layers of the tuning shar
 ap.add_argument("--rows", nargs="+", type=int, default=[129, 128])
 ap.add_argument("--out", default=ts_linear.PLAN_FILE)
 ap.add_argument("--detail", default=None)
+ap.add_argument("--only", nargs="+", default=None, help="projection names (qkv o gate_up down lm_head)")
 args = ap.parse_args()
 
 with open(ts_linear.PLAN_FILE) as f:
@@ -31,10 +32,12 @@ ts_linear._SHIPPED = {}                       # measure, do not look up
 detail = {}
 for tp in args.tp:
     dims = LlamaDims(vocab_size=32000, tp_world=tp, tp_rank=0, **dict(KNOWN_ARCHS[args.arch], num_hidden_layers=args.layers))
+    if tp == 1:
+        dims = LlamaDims(vocab_size=32000, **dict(KNOWN_ARCHS[args.arch], num_hidden_layers=args.layers))
     W = LlamaWeights.random(dims, torch.float16, "cuda:0", seed=1)
     ts = ts_linear.TsLinearSet(W, dims)
     for q in args.rows:
-        for name in ts.NAMES:
+        for name in (args.only or ts.NAMES):
             ts.autotune(name, q)
     for key, rec in ts.tuned.items():
         choice = rec["choice"]
