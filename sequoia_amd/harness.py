@@ -32,7 +32,7 @@ MODELS = {
 }
 
 
-def tp_capturable(target=None) -> bool:
+def tp_capturable(*engines) -> bool:
     """Can the tensor-parallel forward be captured into a hipGraph?  Yes with RCCL (backend "nccl"), without a process
     group, or when the engine runs both collectives on the xGMI kernels (no torch.distributed call in a tree forward);
     not when a gloo collective (through the host) is on the path.  SEQUOIA_TP_GRAPHS=0 forces eager forwards."""
@@ -43,8 +43,10 @@ def tp_capturable(target=None) -> bool:
         return True
     if dist.get_backend() == "nccl":
         return True
-    inner = getattr(target, "engine", None)
-    return bool(getattr(inner, "collectives_capturable", False))
+    # every tensor-parallel engine of the step (the target, and the draft when it is sharded too) must be free of
+    # torch.distributed calls; replicated engines have no collective at all
+    tp = [e.engine for e in engines if e is not None and hasattr(getattr(e, "engine", None), "group")]
+    return bool(tp) and all(getattr(inner, "collectives_capturable", False) for inner in tp)
 
 
 def load_prompts():
@@ -61,14 +63,28 @@ def build(cfg, device, pair, seed_d=1, seed_t=2):
     if cfg.get("tp") and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         from sequoia_amd.Engine import ts_linear
         ts_linear.DETERMINISTIC_PLANS = True       # replicated decisions need identical arithmetic on every rank
+    tp_world = int(os.environ.get("WORLD_SIZE", "1")) if cfg.get("tp") else 1
+    tp_rank = int(os.environ.get("RANK", "0")) if cfg.get("tp") else 0
+    # The 7B draft of configuration E can be sharded like the target (SEQUOIA_TP_DRAFT=1: heads / MLP columns / vocabulary
+    # over the ranks, 2 all-reduces per layer on the xGMI kernel, logits gathered; sampler and verifier stay replicated, the
+    # gathered logits are bit-identical on every rank).  Replicated it streams 13.5 GB per forward on every GPU (3 forwards
+    # per step: about as long as the sharded 70B verify).  Measured per GPU with the tuned shard plans
+    # (profiles/r03_ts_linear_tuning_tp_draft7b.json): at TP = 8 a sharded draft layer is 31 us of projections + ~50 us of
+    # launch-floor kernels and two all-reduces against 97 us replicated -- a wash that depends on the all-reduce latency of
+    # the real links, so the default stays replicated (no collective on the draft path); at TP = 2 sharding wins (the
+    # two-ranks-on-one-GPU run: 76.8 -> 70.2 ms / step).
+    tp_draft = tp_world > 1 and os.environ.get("SEQUOIA_TP_DRAFT", "0") == "1"
     if pair == "calibrated":
         from sequoia_amd.synthetic import calibrated_pair_specs
-        tpw = int(os.environ.get("WORLD_SIZE", "1")) if cfg.get("tp") else 1
-        tpr = int(os.environ.get("RANK", "0")) if cfg.get("tp") else 0
-        dspec, tspec = calibrated_pair_specs(cfg["draft"], cfg["target"], device, tp_world=tpw, tp_rank=tpr)
+        dspec, tspec = calibrated_pair_specs(cfg["draft"], cfg["target"], device, tp_world=tp_world, tp_rank=tp_rank,
+                                             draft_tp=tp_draft)
     else:
         dspec, tspec = f"random:{cfg['draft']}:seed={seed_d}", f"random:{cfg['target']}:seed={seed_t}"
-    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
+    if tp_draft:
+        from sequoia_amd.Engine.tp_engine import TPEngine
+        draft = TPEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
+    else:
+        draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
     if cfg.get("tp"):
         from sequoia_amd.Engine.offload_engine import OffloadEngine
         target = OffloadEngine(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
@@ -97,12 +113,12 @@ class Loop:
         self.attn_mask = torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16, device=device)
         self.position_ids = torch.zeros(M, dtype=torch.long, device=device)
         g, gdev = growmap_on_device(self.grow_map, device)
-        if use_graphs:
+        if use_graphs and (not cfg.get("tp") or tp_capturable(target, draft)):
             lens = sorted({lv.total for lv in g.levels} | {1})
             draft.initialize_cuda_graph(lens, tree_bitmask=gdev["bitmask"], n_tree=g.size)
             # (tensor-parallel target: the verify forward is captured WITH its collectives -- the xGMI all-reduce kernel
             # and RCCL calls are stream-ordered and legal inside a capture; a gloo group is not: eager then)
-            if hasattr(target, "initialize_cuda_graph") and (not cfg.get("tp") or tp_capturable(target)):
+            if hasattr(target, "initialize_cuda_graph") and (not cfg.get("tp") or tp_capturable(target, draft)):
                 target.initialize_cuda_graph([g.size], tree_bitmask=gdev["bitmask"], n_tree=g.size)
         self.pi = 0
         self.tree = None
@@ -111,7 +127,7 @@ class Loop:
         # device-driven steps under tensor parallelism too: the step block, the result ring and the decisions are per
         # rank and identical on every rank (replicated draft / sampler / verifier, same noise), so every rank replays
         # the same whole-step graph -- collectives included -- without any broadcast
-        self.pipelined = bool(pipelined) and str(device).startswith("cuda") and (not cfg.get("tp") or tp_capturable(target))
+        self.pipelined = bool(pipelined) and str(device).startswith("cuda") and (not cfg.get("tp") or tp_capturable(target, draft))
 
     def _new_prompt(self):
         self.draft.clear_kv(); self.target.clear_kv()

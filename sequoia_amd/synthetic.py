@@ -61,8 +61,9 @@ def _weights(arch, device, seed, vocab, embed_full, perms, rank_logits, branch_s
 
 
 def calibrated_pair_specs(draft_arch, target_arch, device, vocab=32000, seed=7, tp_world=1, tp_rank=0,
-                          target_branch=0.04, draft_branch=0.5, draft_blur=0.12):
-    """Returns (draft_spec, target_spec) accepted by the engines' `model_name_or_path`."""
+                          target_branch=0.04, draft_branch=0.5, draft_blur=0.12, draft_tp=False):
+    """Returns (draft_spec, target_spec) accepted by the engines' `model_name_or_path`.  tp_world / tp_rank shard the
+    target (and, with draft_tp, the draft) Megatron-style; every rank derives its shard from the same full matrices."""
     hmax = max(KNOWN_ARCHS[draft_arch]["hidden_size"], KNOWN_ARCHS[target_arch]["hidden_size"])
     gen = torch.Generator(device=device); gen.manual_seed(seed)
     embed_full = torch.randn((vocab, hmax), generator=gen, device=device, dtype=torch.float32)
@@ -73,5 +74,6 @@ def calibrated_pair_specs(draft_arch, target_arch, device, vocab=32000, seed=7, 
         perms.append(inv)                                               # s_k^-1(v)
     logits = _rank_logits(vocab)
     wt = _weights(target_arch, device, 2, vocab, embed_full, perms, logits, target_branch, 0.0, tp_world, tp_rank)
-    wd = _weights(draft_arch, device, 1, vocab, embed_full, perms, logits, draft_branch, draft_blur)
+    wd = _weights(draft_arch, device, 1, vocab, embed_full, perms, logits, draft_branch, draft_blur,
+                  tp_world if draft_tp else 1, tp_rank if draft_tp else 0)
     return dict(weights=wd), dict(weights=wt)

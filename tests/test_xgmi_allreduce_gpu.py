@@ -173,7 +173,7 @@ def test_tp2_on_the_xgmi_allreduce_matches_reference_trace(name, tmp_path, monke
         assert diverged == -1 and matched == 2, f"rank {r}: {matched} steps, diverged at {diverged}"
 
 
-def _tp_pipe_worker(rank, world, port, name, out_dir):
+def _tp_pipe_worker(rank, world, port, name, out_dir, tp_draft=False):
     """Two tensor-parallel ranks on cuda:0 (gloo for the setup only): the whole speculation step -- replicated draft,
     sharded target with BOTH collectives on the xGMI kernels, verifier, compactions -- captured as one hipGraph per rank
     and driven by the device; must commit the synchronous run's tokens on both ranks."""
@@ -196,9 +196,14 @@ def _tp_pipe_worker(rank, world, port, name, out_dir):
     M = meta["M"]
     dspec = dict(state_dict=state_dict_of(z, "draft"), config=dims_dict(meta["draft_dims"], meta["vocab"]))
     tspec = dict(state_dict=state_dict_of(z, "target"), config=dims_dict(meta["target_dims"], meta["vocab"]))
-    draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=dev)
+    if tp_draft:          # the draft sharded like the target (harness.build does this for configuration E)
+        from sequoia_amd.Engine.tp_engine import TPEngine
+        draft = TPEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=dev)
+        assert draft.engine.xgmi is not None and draft.engine.kv_cache.k_cache.shape[2] == max(1, meta["draft_dims"][4] // world)
+    else:
+        draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=dev)
     target = OffloadEngine(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=dev)
-    assert target.engine.xgmi is not None and tp_capturable(target)
+    assert target.engine.xgmi is not None and tp_capturable(target, draft)
     n_steps = int(z["n_steps"]) + 2
     tree = make_tree(z, meta, draft, target, dev)
     want = sync_run(tree, n_steps)
@@ -221,9 +226,9 @@ def _tp_pipe_worker(rank, world, port, name, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["E_64x2", "A_2chain"])
-def test_tp2_whole_step_graph_device_driven_on_xgmi_collectives(name, tmp_path):
+@pytest.mark.parametrize("name,tp_draft", [("E_64x2", False), ("A_2chain", False), ("E_64x2", True), ("B_seq128", True)])
+def test_tp2_whole_step_graph_device_driven_on_xgmi_collectives(name, tp_draft, tmp_path):
     port = 37900 + (os.getpid() % 1500)
-    mp.spawn(_tp_pipe_worker, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_tp_pipe_worker, args=(2, port, name, str(tmp_path), tp_draft), nprocs=2, join=True)
     a = [np.load(tmp_path / f"tp{r}.npy") for r in range(2)]
     assert np.array_equal(a[0], a[1]) and a[0][0] >= 3
