@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libsequoia_hip.so")
-SOURCES = ["kv_ops.hip", "sampler.hip", "verify.hip", "tree_attention.hip", "fused_ops.hip", "ts_linear.hip", "allreduce.hip", "draft_fused.hip"]
+SOURCES = ["kv_ops.hip", "sampler.hip", "verify.hip", "tree_attention.hip", "fused_ops.hip", "ts_linear.hip", "allreduce.hip", "draft_fused.hip", "ts_probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
 # per-source additions.  ts_linear: keep the MFMA accumulators in VGPRs -- with the AGPR form the register
 # allocator permutes the 48-128 accumulator registers on every trip of the ring loop (72 v_accvgpr_* moves
