@@ -385,34 +385,40 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
 }
 
 // One wave.  Walk root -> accepted children; side effects of Tree/SpecTree.py:156,222,224.
-__global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, int token_capacity,
+// Everything the walk reads (per-node verdicts, the tree's tokens, the greedy targets, the children lists) is first loaded
+// into LDS by all 64 lanes at once -- the walk itself (lane 0) then touches no global memory, where every step used to be a
+// dependent round trip -- and the side effects (the -65504 writes of the rejected children, the token compaction, the
+// result record and its ring copy) are issued by the lanes in parallel.
+#define WALK_MAX_CHILD_IDS (2 * SQ_MAX_TREE)
+__global__ void __launch_bounds__(64) verify_walk_kernel(half_t* draft_logits, int64_t* tokens, int token_capacity,
                                    const int32_t* __restrict__ child_off, const int32_t* __restrict__ child_ids,
                                    int n_tree, int vocab, int gt_arg, void* ws_raw, int32_t* result, int mode,
                                    const int64_t* __restrict__ tgt_tokens, int32_t* d_step, int32_t* d_ring) {
     // mode 0: stochastic (Sequoia), 1: token equality against tgt (greedy argmax or caller-supplied samples),
     //      2: stochastic without the draft-logit side effects (SpecInfer)
     const VerifyWs ws = ws_layout(ws_raw, n_tree);
-    if (threadIdx.x != 0) return;
+    const int lane = threadIdx.x;
     const int gt = step_gt(d_step, gt_arg);
+    __shared__ int32_t s_rec[SQ_RESULT_INTS];
     if (d_step && d_step[SQ_STEP_ACTIVE] == 0) {
         // A step that was enqueued behind a terminal one (device-driven loop, steps in flight): it commits nothing.
         // tokens[0, gt) -- the finished text -- and the compacted KV rows stay as the terminal step left them (its gt
         // is the terminal step's accept length, so everything this step's samplers and forwards wrote lies beyond the
         // text); the record says "skipped" and the step block does not move.
-        for (int i = 0; i < SQ_RESULT_INTS; ++i) result[i] = 0;
-        result[SQ_RES_ACCEPT_LEN] = gt;
-        result[SQ_RES_BONUS] = -1;
-        result[SQ_RES_TERMINAL] = 1;
-        result[SQ_RES_REASON] = SQ_REASON_SKIPPED;
-        result[SQ_RES_GT] = gt;
-        result[7] = d_step[SQ_STEP_INDEX];
-        d_step[SQ_STEP_NEXT_GT] = gt;
+        int v = 0;
+        if (lane == SQ_RES_ACCEPT_LEN || lane == SQ_RES_GT) v = gt;
+        if (lane == SQ_RES_BONUS) v = -1;
+        if (lane == SQ_RES_TERMINAL) v = 1;
+        if (lane == SQ_RES_REASON) v = SQ_REASON_SKIPPED;
+        if (lane == 7) v = d_step[SQ_STEP_INDEX];
+        result[lane] = v;
+        if (lane == 0) d_step[SQ_STEP_NEXT_GT] = gt;
         if (d_ring) {
             int32_t* slot = d_ring + ((uint32_t)d_step[SQ_STEP_INDEX] % SQ_RESULT_RING) * SQ_RESULT_INTS;
-            for (int i = 0; i < SQ_RESULT_INTS; ++i)
-                if (i != 7) slot[i] = result[i];
+            if (lane != 7) slot[lane] = v;
             __threadfence_system();
-            __hip_atomic_store(slot + 7, result[7], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __syncthreads();
+            if (lane == 0) __hip_atomic_store(slot + 7, d_step[SQ_STEP_INDEX], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
@@ -420,85 +426,129 @@ __global__ void verify_walk_kernel(half_t* draft_logits, int64_t* tokens, int to
     const int gather_first = greedy || (mode & 4);
     mode &= 3;
     const int64_t* tgt = tgt_tokens ? tgt_tokens : ws.tgt;
-    int node = 0, n_acc = 0, terminal = 0, reason = 0;
-    for (int guard = 0; guard < n_tree; ++guard) {
-        int child = -1, nrej = 0;
-        const int c0 = child_off[node], nc = child_off[node + 1] - c0;
-        if (greedy) {
-            const int64_t want = tgt[node];
-            for (int j = 0; j < nc; ++j) {
-                const int c = child_ids[c0 + j];
-                if (tokens[c + gt - 1] == want) { child = c; break; }
+
+    // ---- stage the walk's inputs in LDS --------------------------------------------------------------------------
+    __shared__ int32_t s_child[SQ_MAX_TREE], s_nrej[SQ_MAX_TREE], s_flag[SQ_MAX_TREE], s_bonus[SQ_MAX_TREE];
+    __shared__ int32_t s_off[SQ_MAX_TREE + 1], s_ids[WALK_MAX_CHILD_IDS];
+    __shared__ int64_t s_tok[SQ_MAX_TREE], s_tgt[SQ_MAX_TREE];
+    __shared__ int32_t s_path[SQ_MAX_TREE], s_walked[SQ_MAX_TREE];       // accepted nodes; every node the walk visited
+    __shared__ int32_t s_out[8];                                           // n_acc, terminal, reason, bonus, last node, n_walked
+    const int n_ids = child_off[n_tree];
+    const bool ids_in_lds = n_ids <= WALK_MAX_CHILD_IDS;
+    for (int t = lane; t < n_tree; t += 64) {
+        if (!greedy) { s_child[t] = ws.child[t]; s_nrej[t] = ws.nrej[t]; s_flag[t] = ws.flag[t]; s_bonus[t] = ws.bonus[t]; }
+        else s_tgt[t] = tgt[t];
+        s_tok[t] = tokens[t + gt - 1];
+        s_off[t] = child_off[t];
+    }
+    if (lane == 0) s_off[n_tree] = n_ids;
+    if (ids_in_lds)
+        for (int i = lane; i < n_ids; i += 64) s_ids[i] = child_ids[i];
+    __syncthreads();
+    auto cid = [&](int i) { return ids_in_lds ? s_ids[i] : child_ids[i]; };
+
+    // ---- the walk (lane 0, LDS only) -------------------------------------------------------------------------------
+    if (lane == 0) {
+        int node = 0, n_acc = 0, terminal = 0, reason = 0, n_walked = 0;
+        for (int guard = 0; guard < n_tree; ++guard) {
+            int child = -1;
+            const int c0 = s_off[node], nc = s_off[node + 1] - c0;
+            s_walked[n_walked++] = node;
+            if (greedy) {
+                const int64_t want = s_tgt[node];
+                for (int j = 0; j < nc; ++j) {
+                    const int c = cid(c0 + j);
+                    if (s_tok[c] == want) { child = c; break; }
+                }
+            } else {
+                child = s_child[node];
             }
-        } else {
-            child = ws.child[node];
-            nrej = ws.nrej[node];
-            // draft_logits[node][token of every rejected child] = finfo(fp16).min
-            for (int j = 0; mode == 0 && j < nrej && j < nc; ++j) {
-                const int64_t tok = tokens[child_ids[c0 + j] + gt - 1];
+            if (child < 0) break;
+            node = child;
+            s_path[n_acc++] = node;
+            const int64_t tk = s_tok[node];
+            if (tk == 0 || tk == 2) { terminal = 1; reason = 1; break; }   // Tree/SpecTree.py:208
+        }
+        int bonus = -1;
+        if (!terminal) {
+            if (greedy) bonus = (int)s_tgt[node];
+            else if (s_flag[node]) { terminal = 1; reason = 2; }            // isnan(residual), :219
+            else bonus = s_bonus[node];
+        }
+        const int a = gt + n_acc;
+        if (!terminal && token_capacity > 0 && a >= token_capacity) {
+            // no slot for the bonus token (a fully accepted chain that ends at max_length): the reference raises
+            // IndexError at `self.tokens[accept_length] = ...` (Tree/SpecTree.py:222); here the step becomes terminal
+            terminal = 1; reason = 3; bonus = -1;
+        }
+        s_out[0] = n_acc; s_out[1] = terminal; s_out[2] = reason; s_out[3] = bonus; s_out[4] = node; s_out[5] = n_walked;
+    }
+    __syncthreads();
+    const int n_acc = s_out[0], terminal = s_out[1], reason = s_out[2], bonus = s_out[3], last = s_out[4], n_walked = s_out[5];
+    const int a = gt + n_acc;
+
+    // ---- side effects, lanes in parallel ---------------------------------------------------------------------------------
+    // draft_logits[node][token of every rejected child] = finfo(fp16).min for every walked node (:156)
+    if (mode == 0 && !greedy) {
+        for (int wi = 0; wi < n_walked; ++wi) {
+            const int node = s_walked[wi];
+            const int c0 = s_off[node], nc = s_off[node + 1] - c0;
+            const int nr = min(s_nrej[node], nc);
+            for (int j = lane; j < nr; j += 64) {
+                const int64_t tok = s_tok[cid(c0 + j)];
                 if (tok >= 0 && tok < vocab) draft_logits[(size_t)node * vocab + tok] = (half_t)(-65504.0f);
             }
         }
-        if (child < 0) break;
-        node = child;
-        ws.path[n_acc] = node;
-        if (n_acc < SQ_RESULT_INTS - SQ_RES_SLOTS) result[SQ_RES_SLOTS + n_acc] = node + gt - 1;
-        result[SQ_RESULT_INTS + n_acc] = node + gt - 1;         // full list (chains deeper than the header)
-        ++n_acc;
-        const int64_t tk = tokens[node + gt - 1];
-        if (tk == 0 || tk == 2) { terminal = 1; reason = 1; break; }   // Tree/SpecTree.py:208
     }
-    int bonus = -1;
-    if (!terminal) {
-        if (greedy) {
-            bonus = (int)tgt[node];
-        } else if (ws.flag[node]) {
-            terminal = 1; reason = 2;                                   // isnan(residual), :219
-        } else {
-            bonus = ws.bonus[node];
-        }
+    // tokens[:a] = tokens[accept_list] and the bonus token at slot a.  Order of the two writes follows the reference:
+    // SpecTree / SpecInferTree store the bonus token at slot a BEFORE the gather (Tree/SpecTree.py:222-224), so an accepted
+    // node that happens to sit at slot a (tree node n_acc + 1 on the accepted path, e.g. a fully accepted 8x8 tree) is
+    // committed with the bonus token's id; GreedyTree / GreedySTree gather first (Tree/GreedyTree.py:204-206).  Reproduced
+    // for token parity; callers that want the lossless order pass SQ_VERIFY_GATHER_FIRST with the bonus uniform.  The
+    // gather reads the staged copies (slots ascending, dst <= src: the sequential in-place move reads original values too).
+    if (!gather_first && !terminal && lane == 0 && n_acc + 1 < n_tree) s_tok[n_acc + 1] = (int64_t)bonus;   // slot a == node n_acc + 1
+    __syncthreads();
+    for (int j = lane; j < n_acc; j += 64) tokens[gt + j] = s_tok[s_path[j]];
+    if (!terminal && lane == 0) tokens[a] = bonus;
+    for (int j = lane; j < n_acc; j += 64) {
+        ws.path[j] = s_path[j];
+        result[SQ_RESULT_INTS + j] = s_path[j] + gt - 1;                    // full list (chains deeper than the header)
     }
-    const int a = gt + n_acc;
-    if (!terminal && token_capacity > 0 && a >= token_capacity) {
-        // no slot for the bonus token (a fully accepted chain that ends at max_length): the reference raises
-        // IndexError at `self.tokens[accept_length] = ...` (Tree/SpecTree.py:222); here the step becomes terminal
-        terminal = 1; reason = 3; bonus = -1;
+    {
+        int v = 0;
+        if (lane == SQ_RES_ACCEPT_LEN) v = a;
+        if (lane == SQ_RES_N_TREE) v = n_acc;
+        if (lane == SQ_RES_BONUS) v = bonus;
+        if (lane == SQ_RES_TERMINAL) v = terminal;
+        if (lane == SQ_RES_REASON) v = reason;
+        if (lane == SQ_RES_GT) v = gt;
+        if (lane == SQ_RES_LAST_NODE) v = last;
+        if (lane == 7) v = d_step ? d_step[SQ_STEP_INDEX] : 0;
+        if (lane >= SQ_RES_SLOTS && lane - SQ_RES_SLOTS < n_acc) v = s_path[lane - SQ_RES_SLOTS] + gt - 1;
+        s_rec[lane] = v;
+        result[lane] = v;
     }
-    // tokens[:a] = tokens[accept_list]: slots ascending and dst <= src, so the sequential
-    // in-place move never overwrites a source it still needs.
-    // Order of the two writes follows the reference: SpecTree / SpecInferTree store the bonus token at slot a
-    // BEFORE the gather (Tree/SpecTree.py:222-224), so an accepted node that happens to sit at slot a (tree node
-    // n_acc + 1 on the accepted path, e.g. a fully accepted 8x8 tree) is committed with the bonus token's id;
-    // GreedyTree / GreedySTree gather first (Tree/GreedyTree.py:204-206).  Reproduced for token parity; callers that
-    // want the lossless order pass SQ_VERIFY_GATHER_FIRST with the bonus uniform.
-    if (!gather_first && !terminal) tokens[a] = bonus;
-    for (int j = 0; j < n_acc; ++j) tokens[gt + j] = tokens[ws.path[j] + gt - 1];
-    if (gather_first && !terminal) tokens[a] = bonus;
-    result[SQ_RES_ACCEPT_LEN] = a;
-    result[SQ_RES_N_TREE] = n_acc;
-    result[SQ_RES_BONUS] = bonus;
-    result[SQ_RES_TERMINAL] = terminal;
-    result[SQ_RES_REASON] = reason;
-    result[SQ_RES_GT] = gt;
-    result[SQ_RES_LAST_NODE] = node;
-    result[7] = d_step ? d_step[SQ_STEP_INDEX] : 0;
     if (d_step) {
-        // device-driven step: the next step starts at new_gt = a + 1 (the bonus token is committed at slot a)
-        // A terminal step leaves gt = a: steps already in flight behind it then work beyond the finished text
-        // (tokens[0, a) and the KV rows compacted to [gt, a) are not touched again) and skip their commit (above).
-        int next = terminal ? a : a + 1;
-        if (terminal && token_capacity > 0 && next + n_tree - 1 > token_capacity) next = gt;     // keep a follower in bounds
-        d_step[SQ_STEP_NEXT_GT] = next;
-        if (terminal) d_step[SQ_STEP_ACTIVE] = 0;
+        const int index = d_step[SQ_STEP_INDEX];
+        __syncthreads();
+        if (lane == 0) {
+            // device-driven step: the next step starts at new_gt = a + 1 (the bonus token is committed at slot a).
+            // A terminal step leaves gt = a: steps already in flight behind it then work beyond the finished text
+            // (tokens[0, a) and the KV rows compacted to [gt, a) are not touched again) and skip their commit (above).
+            int next = terminal ? a : a + 1;
+            if (terminal && token_capacity > 0 && next + n_tree - 1 > token_capacity) next = gt;     // keep a follower in bounds
+            d_step[SQ_STEP_NEXT_GT] = next;
+            if (terminal) d_step[SQ_STEP_ACTIVE] = 0;
+        }
         if (d_ring) {
             // copy of the header for the host, one slot per step.  The ring may live in pinned host memory (the host then
             // polls it instead of waiting on an event): everything but the step-index word first, a system-scope fence,
             // then the index word -- a reader that sees the index sees the record.
-            int32_t* slot = d_ring + ((uint32_t)d_step[SQ_STEP_INDEX] % SQ_RESULT_RING) * SQ_RESULT_INTS;
-            for (int i = 0; i < SQ_RESULT_INTS; ++i)
-                if (i != 7) slot[i] = result[i];
+            int32_t* slot = d_ring + ((uint32_t)index % SQ_RESULT_RING) * SQ_RESULT_INTS;
+            if (lane != 7) slot[lane] = s_rec[lane];
             __threadfence_system();
-            __hip_atomic_store(slot + 7, result[7], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __syncthreads();
+            if (lane == 0) __hip_atomic_store(slot + 7, index, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
