@@ -138,7 +138,7 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
     n = g["size"]
     cfg_d = make_cfg(R, draft_dims, vocab)
     cfg_t = make_cfg(R, target_dims, vocab)
-    big = seeded and target_dims[0] * target_dims[1] * target_dims[2] > (1 << 30)
+    big = seeded and target_dims[0] * target_dims[1] * target_dims[2] > (1 << 27)
     draft = make_engine(R, R["GIE"], R["IE"], R["MM"].LlamaForCausalLM_FI, cfg_d, M, 1, logit_gain, skip_init=big)
     target = make_engine(R, R["GIETG"], R["IETG"], R["MM"].LlamaForCausalLM_TG, cfg_t, M, 2, logit_gain, skip_init=big)
     if share_weights > 0.0:
@@ -516,6 +516,15 @@ def main():
              lead=(768, 3.0), out_dir=out_dir)
     run_case(R, "C_7b", gm("L40_growmaps/8x8-tree.pt"), d68, t7b, 32000, 384, 0.6, "greedy", 128, 4, 41, logit_gain=3.0,
              seeded=True, share_vocab=0.05, compact=16, branch_scale=0.0015, lead=(768, 3.0), out_dir=out_dir)
+    # configuration D at its real WIDTHS (BASELINE.json configs[3]): Sheared-LLaMA-1.3B dims draft (hidden 2048, 16 heads of 128,
+    # inter 5504) -> Llama-2-13b dims target (hidden 5120, 40 heads of 128, inter 13824), 4 layers each (the widths decide
+    # the kernels' shapes and launch plans -- the 13B plans mix the tall-skinny kernel with hipBLASLt -- the depth only
+    # repeats them), the reference's A100-CNN-160m-13b growmap, V = 32000, M = 384, 128-token prompt
+    d13w = (2048, 5504, 4, 16, 16)
+    t13w = (5120, 13824, 4, 40, 40)
+    run_case(R, "D_13b_w4", gm("A100_growmaps/160m_13b/growmaps/A100-CNN-160m-13b-stochastic.pt"), d13w, t13w, 32000, 384, 0.6,
+             "stochastic", 128, 4, 43, logit_gain=1.2, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.005,
+             lead=(2048, 3.0), out_dir=out_dir)
     # the acceptance-rate probes of tests/test_accept.py (fp32 noise, p >= r q in fp32; top-k children / argmax)
     run_probe_case(R, "P_spectest", "spectest", tiny, 1024, 128, 0.6, 8, 16, 12, 31, noise=0.6, out_dir=out_dir)
     run_probe_case(R, "Q_greedytest", "greedytest", tiny, 1024, 128, 0.6, 8, 16, 12, 32, noise=0.6, out_dir=out_dir)

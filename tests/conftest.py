@@ -41,6 +41,8 @@ COMPACT_TRACES = ["V32k_seq128"]        # V = 32000, seeded weights, subsampled 
 # prompt; seeded weights (13.5 GB regenerated on the GPU box), compact logits.  B_7b: SpecTree on the
 # A100-CNN-68m-7b-stochastic growmap; C_7b: GreedyTree on 8x8-tree (+ recorded top-k / top-2 margins)
 HEADLINE_TRACES = ["B_7b", "C_7b"]
+# configuration D at its real widths (1.3B-dims draft -> 13B-dims target: hidden 5120, 40 heads, inter 13824), 4 layers each
+WIDTH_TRACES = ["D_13b_w4"]
 BASELINE_TRACES = ["F_specinfer", "G_greedys"]        # the paper's comparison baselines (SpecInferTree, GreedySTree)
 
 

@@ -51,7 +51,7 @@ def build_engines(z, meta, device):
     from sequoia_amd.Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
     M = meta["M"]
     sm = meta.get("seeded")
-    big = bool(sm) and meta["target_dims"][0] * meta["target_dims"][1] * meta["target_dims"][2] > (1 << 30)
+    big = bool(sm) and meta["target_dims"][0] * meta["target_dims"][1] * meta["target_dims"][2] > (1 << 27)
     key = None
     if big:
         key = (str(device), tuple(meta["draft_dims"]), tuple(meta["target_dims"]), meta["vocab"], M, meta["logit_gain"],

@@ -11,14 +11,14 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import COMPACT_TRACES, HEADLINE_TRACES, TRACE_NAMES, load_trace
+from conftest import COMPACT_TRACES, HEADLINE_TRACES, TRACE_NAMES, WIDTH_TRACES, load_trace
 from helpers import assert_replay_complete, build_engines, check_replay, make_tree, replay_trace
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("name", TRACE_NAMES + COMPACT_TRACES + HEADLINE_TRACES)
+@pytest.mark.parametrize("name", TRACE_NAMES + COMPACT_TRACES + HEADLINE_TRACES + WIDTH_TRACES)
 def test_gpu_loop_reproduces_reference_tokens(name):
     """All steps of every trace (configs A-E shapes, the demo tree, the V = 32000 trace, and the two traces at the
     headline model dims: 68m -> Llama-2-7b architectures, SpecTree 128-node growmap and GreedyTree 8x8).  Logits agree within
