@@ -525,6 +525,13 @@ def main():
     run_case(R, "D_13b_w4", gm("A100_growmaps/160m_13b/growmaps/A100-CNN-160m-13b-stochastic.pt"), d13w, t13w, 32000, 384, 0.6,
              "stochastic", 128, 4, 43, logit_gain=1.2, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.005,
              lead=(2048, 3.0), out_dir=out_dir)
+    # configuration E at its real WIDTHS (BASELINE.json configs[4]): Llama-2-7b-dims draft -> Llama-2-70b-dims target (hidden
+    # 8192, 64 query heads / 8 KV heads of 128: GQA 8:1, inter 28672), 2 layers each, the 129-node 64x2 tree (9 row tiles),
+    # V = 32000: single GPU and tensor-parallel (KV-head split) replays
+    d7w = (4096, 11008, 2, 32, 32)
+    t70w = (8192, 28672, 2, 64, 8)
+    run_case(R, "E_70b_w2", gm("L40_growmaps/64x2-tree.pt"), d7w, t70w, 32000, 384, 0.6, "stochastic", 128, 3, 44,
+             logit_gain=0.5, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.003, lead=(4096, 4.0), out_dir=out_dir)
     # the acceptance-rate probes of tests/test_accept.py (fp32 noise, p >= r q in fp32; top-k children / argmax)
     run_probe_case(R, "P_spectest", "spectest", tiny, 1024, 128, 0.6, 8, 16, 12, 31, noise=0.6, out_dir=out_dir)
     run_probe_case(R, "Q_greedytest", "greedytest", tiny, 1024, 128, 0.6, 8, 16, 12, 32, noise=0.6, out_dir=out_dir)

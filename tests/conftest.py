@@ -42,7 +42,8 @@ COMPACT_TRACES = ["V32k_seq128"]        # V = 32000, seeded weights, subsampled 
 # A100-CNN-68m-7b-stochastic growmap; C_7b: GreedyTree on 8x8-tree (+ recorded top-k / top-2 margins)
 HEADLINE_TRACES = ["B_7b", "C_7b"]
 # configuration D at its real widths (1.3B-dims draft -> 13B-dims target: hidden 5120, 40 heads, inter 13824), 4 layers each
-WIDTH_TRACES = ["D_13b_w4"]
+# configuration E at its real widths (7B-dims draft -> 70B-dims target: hidden 8192, GQA 64:8, inter 28672), 2 layers each
+WIDTH_TRACES = ["D_13b_w4", "E_70b_w2"]
 BASELINE_TRACES = ["F_specinfer", "G_greedys"]        # the paper's comparison baselines (SpecInferTree, GreedySTree)
 
 

@@ -31,6 +31,25 @@ def trace_state_dicts(z, meta):
     if not sm:
         return state_dict_of(z, "draft"), state_dict_of(z, "target")
     from oracle import seeded_weights as SW
+    # Large seeded models (seconds to minutes of CPU generation) are cached on local disk: the tensor-parallel tests spawn
+    # fresh processes per rank and per test, each of which would regenerate the same weights (RAM-backed /dev/shm).  The cache entry is written
+    # only after the checksums of a fresh generation matched the trace, and is keyed by everything that defines the weights.
+    import hashlib
+    import os
+    n_params = sum(d[0] * d[1] * d[2] * 3 for d in (meta["target_dims"], meta["draft_dims"]))
+    cache = None
+    if n_params > (1 << 27):
+        key = hashlib.sha256(json.dumps([meta["target_dims"], meta["draft_dims"], meta["vocab"], meta["logit_gain"], sm],
+                                        sort_keys=True).encode()).hexdigest()[:20]
+        cdir = os.environ.get("SEQUOIA_TEST_CACHE", "/dev/shm/sequoia_test_cache" if os.path.isdir("/dev/shm") else "/tmp/sequoia_test_cache")
+        cache = os.path.join(cdir, f"seeded_{key}.pt")
+        if os.path.exists(cache):
+            try:
+                blob = torch.load(cache, map_location="cpu", weights_only=True, mmap=True)
+                if blob["checks"] == [sm["draft_checksum"], sm["target_checksum"]]:
+                    return blob["draft"], blob["target"]
+            except Exception:
+                pass                                   # unreadable / partial file: regenerate
     sd_t = SW.seeded_state_dict(tuple(meta["target_dims"]), meta["vocab"], sm["target_seed"], meta["logit_gain"],
                                   branch_scale=sm.get("branch_scale", 1.0), lead=sm.get("lead"))
     sd_d = SW.seeded_state_dict(tuple(meta["draft_dims"]), meta["vocab"], sm["draft_seed"], meta["logit_gain"],
@@ -39,6 +58,14 @@ def trace_state_dicts(z, meta):
         SW.correlate(sd_d, sd_t, sm["share_vocab"], sm["share_seed"])
     assert str(SW.checksum(sd_d)) == sm["draft_checksum"] and str(SW.checksum(sd_t)) == sm["target_checksum"], \
         "seeded weights differ from the ones the reference trace was generated with (torch CPU generator drift)"
+    if cache is not None and n_params < (3 << 30):         # (the 7B-dims pair is shared in-process instead: 27 GB on disk)
+        try:
+            os.makedirs(os.path.dirname(cache), exist_ok=True)
+            tmp = cache + f".{os.getpid()}.tmp"
+            torch.save(dict(draft=sd_d, target=sd_t, checks=[sm["draft_checksum"], sm["target_checksum"]]), tmp)
+            os.replace(tmp, cache)
+        except OSError:
+            pass
     return sd_d, sd_t
 
 

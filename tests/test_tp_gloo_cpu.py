@@ -21,7 +21,7 @@ def _worker(rank, world, port, name, out_dir, device="cpu"):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from conftest import load_trace
-    from helpers import check_replay, dims_dict, make_tree, state_dict_of
+    from helpers import check_replay, dims_dict, make_tree, trace_state_dicts
     from oracle.ops_adapter import OracleOps
     from sequoia_amd import ops
     from sequoia_amd.Engine.Engine import GraphInferenceEngine
@@ -30,8 +30,9 @@ def _worker(rank, world, port, name, out_dir, device="cpu"):
         ops.set_ops_for_testing(OracleOps())      # (on a GPU the HIP kernels run: tests/test_tp_world2_gpu.py)
     z, meta = load_trace(name)
     M = meta["M"]
-    dspec = dict(state_dict=state_dict_of(z, "draft"), config=dims_dict(meta["draft_dims"], meta["vocab"]))
-    tspec = dict(state_dict=state_dict_of(z, "target"), config=dims_dict(meta["target_dims"], meta["vocab"]))
+    sd_d, sd_t = trace_state_dicts(z, meta)          # stored arrays, or regenerated from the recorded seeds
+    dspec = dict(state_dict=sd_d, config=dims_dict(meta["draft_dims"], meta["vocab"]))
+    tspec = dict(state_dict=sd_t, config=dims_dict(meta["target_dims"], meta["vocab"]))
     draft = GraphInferenceEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=device)
     target = OffloadEngine(max_length=M, model_name_or_path=tspec, dtype=torch.float16, device=device)
     assert target.world == world and target.engine.kv_cache.k_cache.shape[2] == max(1, meta["target_dims"][4] // world)

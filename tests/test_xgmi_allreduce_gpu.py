@@ -158,7 +158,7 @@ def test_missing_peer_times_out_instead_of_hanging(tmp_path, monkeypatch):
     assert int(np.load(tmp_path / "lonely.npy")[0]) & 1 == 1
 
 
-@pytest.mark.parametrize("name", ["E_64x2"])
+@pytest.mark.parametrize("name", ["E_64x2", "E_70b_w2"])
 def test_tp2_on_the_xgmi_allreduce_matches_reference_trace(name, tmp_path, monkeypatch):
     """The tensor-parallel target (KV-head split, vocabulary-parallel lm_head) with its row-parallel projections reduced
     by the xGMI kernel: every step of the reference's trace on both ranks (tests/test_tp_gloo_cpu.py::_worker asserts
@@ -168,9 +168,11 @@ def test_tp2_on_the_xgmi_allreduce_matches_reference_trace(name, tmp_path, monke
     monkeypatch.setenv("SEQUOIA_TP_REQUIRE_XGMI", "1")
     port = 36300 + (os.getpid() % 1500)
     mp.spawn(_worker, args=(2, port, name, str(tmp_path), "cuda:0"), nprocs=2, join=True)
+    from conftest import load_trace
+    n_steps = int(load_trace(name)[0]["n_steps"])
     for r in range(2):
         matched, diverged = np.load(tmp_path / f"r{r}.npy")
-        assert diverged == -1 and matched == 2, f"rank {r}: {matched} steps, diverged at {diverged}"
+        assert diverged == -1 and matched == n_steps, f"rank {r}: {matched} steps, diverged at {diverged}"
 
 
 def _tp_pipe_worker(rank, world, port, name, out_dir, tp_draft=False):
@@ -186,7 +188,7 @@ def _tp_pipe_worker(rank, world, port, name, out_dir, tp_draft=False):
     torch.cuda.set_device(0)
     dev = "cuda:0"
     from conftest import load_trace
-    from helpers import dims_dict, make_tree, pipelined_run, state_dict_of, sync_run
+    from helpers import dims_dict, make_tree, pipelined_run, sync_run, trace_state_dicts
     from sequoia_amd.Engine import ts_linear
     from sequoia_amd.Engine.Engine import GraphInferenceEngine
     from sequoia_amd.Engine.offload_engine import OffloadEngine
@@ -194,8 +196,9 @@ def _tp_pipe_worker(rank, world, port, name, out_dir, tp_draft=False):
     ts_linear.DETERMINISTIC_PLANS = True
     z, meta = load_trace(name)
     M = meta["M"]
-    dspec = dict(state_dict=state_dict_of(z, "draft"), config=dims_dict(meta["draft_dims"], meta["vocab"]))
-    tspec = dict(state_dict=state_dict_of(z, "target"), config=dims_dict(meta["target_dims"], meta["vocab"]))
+    sd_d, sd_t = trace_state_dicts(z, meta)
+    dspec = dict(state_dict=sd_d, config=dims_dict(meta["draft_dims"], meta["vocab"]))
+    tspec = dict(state_dict=sd_t, config=dims_dict(meta["target_dims"], meta["vocab"]))
     if tp_draft:          # the draft sharded like the target (harness.build does this for configuration E)
         from sequoia_amd.Engine.tp_engine import TPEngine
         draft = TPEngine(max_length=M, model_name_or_path=dspec, dtype=torch.float16, device=dev)
@@ -226,7 +229,8 @@ def _tp_pipe_worker(rank, world, port, name, out_dir, tp_draft=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,tp_draft", [("E_64x2", False), ("A_2chain", False), ("E_64x2", True), ("B_seq128", True)])
+@pytest.mark.parametrize("name,tp_draft", [("E_64x2", False), ("A_2chain", False), ("E_64x2", True), ("B_seq128", True),
+                                           ("E_70b_w2", False), ("E_70b_w2", True)])
 def test_tp2_whole_step_graph_device_driven_on_xgmi_collectives(name, tp_draft, tmp_path):
     port = 37900 + (os.getpid() % 1500)
     mp.spawn(_tp_pipe_worker, args=(2, port, name, str(tmp_path), tp_draft), nprocs=2, join=True)
