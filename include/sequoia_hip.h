@@ -397,6 +397,11 @@ int sq_ar_ipc_close(void* ptr);
 int sq_ar_status(const void* own_ws, int* status);      /* 0 ok; bit 0 / 1: a phase-1 / phase-2 flag never arrived (host sync) */
 int sq_allreduce_sum_f16(void* data, size_t n, int rank, int world, void* const* ws, size_t max_elems, int blocks,
                          void* stream);
+/* The same all-reduce fed by a split-K row-parallel projection: slab = fp32 [splits][n] partial products of this rank
+ * (sq_linear_ts_f16, splits > 1); the rank's contribution is h(sum_s slab[s]) -- the fp16 rows sq_add_rmsnorm_slabs_f16
+ * would have materialised first -- and `out` [n] fp16 receives the sum over the ranks (one launch instead of two).      */
+int sq_allreduce_sum_slabs_f16(const void* slab, int splits, void* out, size_t n, int rank, int world, void* const* ws,
+                               size_t max_elems, int blocks, void* stream);
 /* All-gather of the vocabulary-parallel lm_head (column-parallel over the ranks, Engine/Llama_model.py:280-283 on a
  * shard): slice = this rank's [rows][v] fp16 logits, out = the full [rows][world v] rows (rank r's columns at
  * [r v, (r + 1) v)), by direct peer stores into the same workspaces (their own area: rows world v <=

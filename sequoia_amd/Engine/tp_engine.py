@@ -46,6 +46,8 @@ class _TPInner(InferenceEngineTG):
             # (world 1 with SEQUOIA_TP_FORCE_HOOKS=1: a single-GPU box still runs every hook, RCCL call and capture)
             self.model.reduce_fn = self._all_reduce
             self.model.gather_logits_fn = self._gather_vocab
+            if self.xgmi is not None:
+                self.model.reduce_slabs_fn = self._all_reduce_slabs
 
     def _all_reduce(self, x):
         self.collectives += 1
@@ -54,6 +56,13 @@ class _TPInner(InferenceEngineTG):
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x
+
+    def _all_reduce_slabs(self, slab, splits, rows):
+        """rows <- all-reduce of h(sum of this rank's split-K partials): the slab -> rows pass and the all-reduce in one kernel."""
+        if self.xgmi is None or not self.xgmi.fits(rows):
+            return None
+        self.collectives += 1
+        return self.xgmi.reduce_slabs(slab, splits, rows)
 
     @property
     def collectives_capturable(self):

@@ -393,6 +393,9 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
             return pending
         if pending[0] == "slab":
             rows = torch.empty((q_len, hidden), dtype=dt, device=dev)
+            slabs_fn = getattr(model, "reduce_slabs_fn", None)
+            if slabs_fn is not None and slabs_fn(slab, pending[1], rows) is not None:
+                return ("rows", rows)            # xGMI kernel: slab sum + all-reduce in one launch
             ops.add_rmsnorm_slabs(slab, pending[1], ts._zero_rows[:q_len], rows, None, None, eps)
         else:
             rows = pending[1]

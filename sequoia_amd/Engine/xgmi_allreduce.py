@@ -134,6 +134,17 @@ class XgmiAllReduce:
         self.calls += 1
         return x
 
+    def reduce_slabs(self, slab: torch.Tensor, splits: int, out: torch.Tensor, blocks: int = 0) -> torch.Tensor:
+        """out[n] (fp16) = sum over the ranks of h(sum_s slab[s][n]): the all-reduce of a split-K row-parallel projection
+        straight from its fp32 partials (slab: [>= splits * n] fp32, n = out.numel())."""
+        n = out.numel()
+        assert slab.dtype == torch.float32 and slab.numel() >= splits * n and out.dtype == torch.float16 and out.is_contiguous()
+        native.check(self.lib.sq_allreduce_sum_slabs_f16(slab.data_ptr(), int(splits), out.data_ptr(), n, self.rank, self.world,
+                                                         self._table, self.max_elems, int(blocks),
+                                                         torch.cuda.current_stream().cuda_stream), "sq_allreduce_sum_slabs_f16")
+        self.calls += 1
+        return out
+
     def gather_cols(self, slice_: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """[rows, v] per rank -> [rows, world v] on every rank (rank r's columns at [r v, (r + 1) v))."""
         rows, v = slice_.shape

@@ -46,7 +46,10 @@ __host__ __device__ static inline ArLayout ar_layout(int world, size_t max_elems
 }
 
 struct ArParams {
-    half_t* data;                    // [n] in / out (local)
+    const float* slab;               // optional input: fp32 split-K partials [splits][n]; the rank's rows are h(sum_s slab[s])
+    int splits;
+    size_t split_stride;
+    half_t* data;                    // [n] in / out (local); out only when slab != null
     char* ws[AR_MAX_WORLD];          // workspace of every rank as mapped in THIS process (ws[rank] = own)
     size_t n, max_elems;
     int rank, world, blocks;
@@ -67,6 +70,22 @@ __device__ __forceinline__ bool ar_flag_wait(const uint32_t* p, uint32_t want, u
         __builtin_amdgcn_s_sleep(4);
     }
     return false;
+}
+
+// this rank's 8 input elements at vector g: the caller's fp16 rows, or the fp16 rounding of the split-K partial sums (summed
+// in split order: exactly the rows sq_add_rmsnorm_slabs_f16 would have materialised first)
+__device__ __forceinline__ half8 ar_input(const ArParams& P, size_t g) {
+    if (!P.slab) return *(const half8*)(P.data + g * 8);
+    const float* sp = P.slab + g * 8;
+    floatx4 a = *(const floatx4*)sp, b = *(const floatx4*)(sp + 4);
+    for (int s = 1; s < P.splits; ++s) {
+        a += *(const floatx4*)(sp + s * P.split_stride);
+        b += *(const floatx4*)(sp + s * P.split_stride + 4);
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = (half_t)a[j]; o[4 + j] = (half_t)b[j]; }
+    return o;
 }
 
 __global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const ArParams P) {
@@ -91,7 +110,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const Ar
         half_t* dst = (half_t*)(P.ws[p] + L.area_a) + (size_t)R * L.chunk_cap;
         for (size_t v = v0 + tid; v < v1; v += AR_THREADS) {
             const size_t g = (size_t)p * vec_per_chunk + v;
-            if (g < n_vec) *(u32x4*)(dst + v * 8) = *(const u32x4*)(P.data + g * 8);
+            if (g < n_vec) *(half8*)(dst + v * 8) = ar_input(P, g);
         }
     }
     __threadfence_system();
@@ -115,7 +134,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const Ar
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
             for (int p = 0; p < W; ++p) {
-                const half8 x = p == R ? *(const half8*)(P.data + g * 8)
+                const half8 x = p == R ? ar_input(P, g)
                                        : __builtin_nontemporal_load((const half8*)(a + (size_t)p * L.chunk_cap + v * 8));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += (float)x[j];
@@ -198,16 +217,31 @@ extern "C" int sq_ar_status(const void* own_ws, int* status) {
     return hipMemcpy(status, own_ws, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess ? SQ_OK : SQ_ELAUNCH;
 }
 
+static int ar_launch(const float* slab, int splits, void* data, size_t n, int rank, int world, void* const* ws, size_t max_elems,
+                     int blocks, void* stream);
+
 extern "C" int sq_allreduce_sum_f16(void* data, size_t n, int rank, int world, void* const* ws, size_t max_elems, int blocks,
                                     void* stream) {
+    return ar_launch(nullptr, 0, data, n, rank, world, ws, max_elems, blocks, stream);
+}
+
+extern "C" int sq_allreduce_sum_slabs_f16(const void* slab, int splits, void* out, size_t n, int rank, int world, void* const* ws,
+                                          size_t max_elems, int blocks, void* stream) {
+    if (!slab || splits < 1 || ((uintptr_t)slab & 15)) return SQ_EINVAL;
+    return ar_launch((const float*)slab, splits, out, n, rank, world, ws, max_elems, blocks, stream);
+}
+
+static int ar_launch(const float* slab, int splits, void* data, size_t n, int rank, int world, void* const* ws, size_t max_elems,
+                     int blocks, void* stream) {
     if (!data || !ws || world < 1 || world > AR_MAX_WORLD || rank < 0 || rank >= world || n == 0) return SQ_EINVAL;
     if (n > max_elems || (n & 7) || ((uintptr_t)data & 15)) return SQ_EUNSUPPORTED;
-    if (world == 1) return SQ_OK;
     ArParams P;
+    P.slab = slab; P.splits = splits; P.split_stride = n;
     P.data = (half_t*)data; P.n = n; P.max_elems = max_elems; P.rank = rank; P.world = world;
     for (int i = 0; i < AR_MAX_WORLD; ++i) P.ws[i] = i < world ? (char*)ws[i] : nullptr;
     for (int i = 0; i < world; ++i)
         if (!P.ws[i]) return SQ_EINVAL;
+    if (world == 1) return slab ? SQ_EUNSUPPORTED : SQ_OK;
     if (blocks <= 0) {
         // one block per 4 KB of a chunk keeps a block's three phases short (the flags are per block) without starving the
         // links: 2.1 MB over 8 ranks = 264 KB chunks -> 64 blocks; tiny messages take one

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "sq_ar_ipc_close": (_i, [_vp]),
     "sq_ar_status": (_i, [_vp, C.POINTER(_i)]),
     "sq_allreduce_sum_f16": (_i, [_vp, C.c_size_t, _i, _i, C.POINTER(_vp), C.c_size_t, _i, _vp]),
+    "sq_allreduce_sum_slabs_f16": (_i, [_vp, _i, _vp, C.c_size_t, _i, _i, C.POINTER(_vp), C.c_size_t, _i, _vp]),
     "sq_allgather_cols_f16": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(_vp), C.c_size_t, C.c_size_t, _vp]),
 }
 

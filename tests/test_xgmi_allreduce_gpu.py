@@ -65,6 +65,19 @@ def _ar_worker(rank, world, port, out_dir):
         assert ar.status() == 0
         assert torch.equal(got, torch.cat(parts, dim=1)) and torch.equal(got2, got), f"gather {rows} x {v}"
         assert float(y[0]) == world * world
+    # 1c. the all-reduce fed by split-K partials (fp32 slabs) == fp16 rounding of the slab sum, then the plain all-reduce
+    for i, (rows, hid, splits) in enumerate([(129, 8192, 2), (34, 768, 3), (1, 4096, 4)]):
+        gen.manual_seed(900 + 7 * i + rank)
+        slab = torch.randn(splits, rows * hid, generator=gen).to(dev)
+        acc = slab[0].clone()
+        for sidx in range(1, splits):
+            acc += slab[sidx]
+        ref = acc.half()
+        ar(ref)
+        out = torch.empty(rows * hid, dtype=torch.float16, device=dev)
+        ar.reduce_slabs(slab.reshape(-1), splits, out)
+        torch.cuda.synchronize()
+        assert ar.status() == 0 and torch.equal(out, ref), f"slab all-reduce {rows} x {hid} x {splits}"
     # 2. a burst of back-to-back calls without host synchronisation, arrival skewed (one rank is kept busy / asleep):
     #    call k + 1 of the fast rank must not disturb call k of the slow one (per-block epochs, areas reused every call)
     n = 129 * 8192
