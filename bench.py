@@ -341,12 +341,12 @@ def tp_extra(n: int, args) -> dict:
     first = _tp_child(n, args, {})
     if "error" not in first:
         return first
-    second = _tp_child(n, args, {"SEQUOIA_TP_ALLREDUCE": "rccl"})
+    second = _tp_child(n, args, {"SEQUOIA_TP_ALLREDUCE": "rccl"}, timeout_s=int(os.environ.get("SEQUOIA_TP_RETRY_TIMEOUT", "150")))
     second["first_attempt"] = dict(collectives="xgmi", **{k: first[k] for k in ("error", "stderr") if k in first})
     return second
 
 
-def _tp_child(n: int, args, extra_env: dict) -> dict:
+def _tp_child(n: int, args, extra_env: dict, timeout_s: int = 0) -> dict:
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--config", "E", "--steps", str(min(args.steps, 12)),
            "--warmup", "2", "--no-cpu-baseline", "--no-autoregressive", "--no-tuned-growmap", "--no-tp-extra",
@@ -362,7 +362,7 @@ def _tp_child(n: int, args, extra_env: dict) -> dict:
     # own session: on a timeout the whole tree (launcher + ranks) is killed by process group, nothing keeps a GPU
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
     try:
-        so, se = proc.communicate(timeout=int(os.environ.get("SEQUOIA_TP_EXTRA_TIMEOUT", "240")))
+        so, se = proc.communicate(timeout=timeout_s or int(os.environ.get("SEQUOIA_TP_EXTRA_TIMEOUT", "240")))
     except subprocess.TimeoutExpired:
         try:
             os.killpg(proc.pid, signal.SIGKILL)
