@@ -7,12 +7,18 @@
 // disappears -- together with the residual-add launch in front of it once o_proj / down_proj write the residual stream
 // through the tall-skinny kernel's "+ residual" epilogue (ts_linear.hip, splits == 1).  Per level of the 68m draft:
 // 4 norm launches + the final norm + (optionally) the embedding launch are gone.
+// MEASURED (profiles/r03_draft_fused_not_adopted.md): not faster than the unfused 19-launch sequence (96 vs 88 us at 34 rows)
+// -- every unfused kernel already sits at the ~4.7 us floor of a dependent graph node and the fused body is the sum of the
+// two dependency chains it replaces.  Opt-in (SEQUOIA_DRAFT_FUSED=1), kept with its tests as the record of the experiment.
 //
 //   dn_linear_kernel<MT, NT, EPI>:  out = epilogue( RMSNorm(x) * g  @  W^T )
-//     prologue  x (row-major residual stream, or embed[ids] for the first layer) -> registers: lane (r = lane % 16,
-//               cg = lane / 16) of wave mt holds chunks cg, cg + 4, ... of row 16 mt + r; sum of squares over the 4
-//               lanes of a row (fp32), h(x * rstd) -> h(g * .) (the rounding points of Engine/Llama_modules.py:282-288),
-//               written fragment-major into LDS (one conflict-free 1 KB store per wave instruction);
+//     prologue  x (row-major residual stream, or embed[ids] for the first layer) -> registers, all 4 waves: wave w takes the
+//               k-steps w, w + 4, ...; lane (r = lane % 16, cg = lane / 16) holds chunk 4 i + cg of row 16 mt + r for every
+//               row tile; sum of squares over the row's 4 lanes, then over the 4 waves through LDS (fixed order, fp32),
+//               h(x * rstd) -> h(g * .) (the rounding points of Engine/Llama_modules.py:282-288), written fragment-major into
+//               LDS (one conflict-free 1 KB store per wave instruction).  Straight-line per K (a switch over K / 128): a
+//               predicate around the loads makes the compiler drain vmcnt at every join (measured: 14 vs 8 us per launch).
+//               The wave's first weight loads are issued before the prologue;
 //     main      the 4 waves split K; weights stream from the fragment-major image of ts_linear (same repack, same
 //               HBM / L2 access pattern) straight into MFMA B registers, A fragments come from LDS;
 //     epilogue  the 4 K-partials meet in LDS (the activation image is dead by then) and are summed in wave order:
