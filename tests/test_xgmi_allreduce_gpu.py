@@ -51,7 +51,8 @@ def _ar_worker(rank, world, port, out_dir):
         assert torch.equal(lo, hi), f"n = {n}: ranks hold different bits"
         res["sizes"].append(n)
     # 1b. all-gather of column-parallel logits: [rows, v] per rank -> [rows, W v], exact, interleaved with all-reduces
-    for i, (rows, v) in enumerate([(1, 16000), (129, 16000), (34, 8), (144, 16000)]):
+    vs = 32000 // world
+    for i, (rows, v) in enumerate([(1, vs), (129, vs), (34, 8), (144, vs)]):
         gen.manual_seed(400 + 3 * i + rank)
         sl = torch.randn(rows, v, generator=gen).half().to(dev)
         parts = [torch.empty_like(sl) for _ in range(world)]
@@ -90,9 +91,9 @@ def _ar_worker(rank, world, port, out_dir):
     torch.cuda.synchronize(); dist.barrier()
     big = torch.randn(4096, 4096, device=dev)
     for k in range(24):
-        if k % 5 == rank:
+        if k % 5 == rank % 5:
             time.sleep(0.02)                       # host-side skew
-        if k % 7 == 3 * rank:
+        if k % 7 == (3 * rank) % 7:
             big = big @ big * 1e-4                 # device-side skew: this rank's kernel is queued behind a GEMM
         ar(xs[k])
     torch.cuda.synchronize()
@@ -135,10 +136,13 @@ def _ar_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_shot_allreduce_two_ranks_one_gpu(tmp_path):
-    port = 33100 + (os.getpid() % 1500)
-    mp.spawn(_ar_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_shot_allreduce_ranks_on_one_gpu(world, tmp_path):
+    """world 4: three peers per rank -- the staggered peer order, the rank-order sum over more than two copies and the
+    per-(peer, block) flags of a larger group, still on the one GPU."""
+    port = 33100 + (os.getpid() % 1500) + world
+    mp.spawn(_ar_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
         sizes, burst, graph, calls = np.load(tmp_path / f"ar{r}.npy")
         assert sizes == 7 and burst == 1 and graph == 1 and calls > 40
 
@@ -171,21 +175,24 @@ def test_missing_peer_times_out_instead_of_hanging(tmp_path, monkeypatch):
     assert int(np.load(tmp_path / "lonely.npy")[0]) & 1 == 1
 
 
-@pytest.mark.parametrize("name", ["E_64x2", "E_70b_w2"])
-def test_tp2_on_the_xgmi_allreduce_matches_reference_trace(name, tmp_path, monkeypatch):
+@pytest.mark.parametrize("name,world", [("E_64x2", 2), ("E_70b_w2", 2), ("E_64x2", 4), ("E_70b_w2", 4)])
+def test_tp_on_the_xgmi_allreduce_matches_reference_trace(name, world, tmp_path, monkeypatch):
     """The tensor-parallel target (KV-head split, vocabulary-parallel lm_head) with its row-parallel projections reduced
     by the xGMI kernel: every step of the reference's trace on both ranks (tests/test_tp_gloo_cpu.py::_worker asserts
     identical decisions on both ranks)."""
     from test_tp_gloo_cpu import _worker
     monkeypatch.setenv("SEQUOIA_TP_ALLREDUCE", "xgmi")
     monkeypatch.setenv("SEQUOIA_TP_REQUIRE_XGMI", "1")
-    port = 36300 + (os.getpid() % 1500)
-    mp.spawn(_worker, args=(2, port, name, str(tmp_path), "cuda:0"), nprocs=2, join=True)
+    port = 36300 + (os.getpid() % 1500) + world
+    mp.spawn(_worker, args=(world, port, name, str(tmp_path), "cuda:0"), nprocs=world, join=True)
     from conftest import load_trace
     n_steps = int(load_trace(name)[0]["n_steps"])
-    for r in range(2):
-        matched, diverged = np.load(tmp_path / f"r{r}.npy")
-        assert diverged == -1 and matched == n_steps, f"rank {r}: {matched} steps, diverged at {diverged}"
+    res = [tuple(np.load(tmp_path / f"r{r}.npy")) for r in range(world)]
+    assert len(set(res)) == 1, res                           # every rank: the same outcome
+    matched, diverged = res[0]
+    # all steps token-identical to the reference, or (4-way sharded sums round differently from the reference's unsharded
+    # GEMM) a first differing decision that the worker has proven to sit inside one fp16 ulp (assert_replay_complete)
+    assert (diverged == -1 and matched == n_steps) or (world > 2 and diverged >= 0), res
 
 
 def _tp_pipe_worker(rank, world, port, name, out_dir, tp_draft=False):
