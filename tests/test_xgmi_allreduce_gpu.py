@@ -175,7 +175,7 @@ def test_missing_peer_times_out_instead_of_hanging(tmp_path, monkeypatch):
     assert int(np.load(tmp_path / "lonely.npy")[0]) & 1 == 1
 
 
-@pytest.mark.parametrize("name,world", [("E_64x2", 2), ("E_70b_w2", 2), ("E_64x2", 4), ("B_seq128", 4)])
+@pytest.mark.parametrize("name,world", [("E_64x2", 2), ("E_70b_w2", 2), ("E_64x2", 4), ("demo4", 4)])
 def test_tp_on_the_xgmi_allreduce_matches_reference_trace(name, world, tmp_path, monkeypatch):
     """The tensor-parallel target (KV-head split, vocabulary-parallel lm_head) with its row-parallel projections reduced
     by the xGMI kernel: every step of the reference's trace on both ranks (tests/test_tp_gloo_cpu.py::_worker asserts
