@@ -267,10 +267,12 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
         # the build container: the reference checkout does not travel): seconds-per-step ratio, to scale `value`
         ref_over_port = None
         try:
-            with open(os.path.join(REPO, "profiles", "r02_cpu_reference_vs_port.json")) as f:
+            import glob
+            newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_cpu_reference_vs_port.json")))[-1]
+            with open(newest) as f:
                 rp = json.load(f)
             ref_over_port = rp["reference"]["steps_per_s"] / rp["port"]["steps_per_s"]
-        except (OSError, KeyError, ValueError, ZeroDivisionError):
+        except (OSError, KeyError, ValueError, ZeroDivisionError, IndexError):
             pass
         return dict(value=(tok_per_step / best_s) if n_steady else None, unit="tokens/s", cores=best_thr,
                     kind="port", commit_order=COMMIT_ORDER,
