@@ -408,6 +408,16 @@ int sq_allreduce_sum_slabs_f16(const void* slab, int splits, void* out, size_t n
  * max_gather_elems, the value the workspace was sized with).  v % 8 == 0.                                          */
 int sq_allgather_cols_f16(const void* slice, void* out, int rows, int v, int rank, int world, void* const* ws,
                           size_t max_elems, size_t max_gather_elems, void* stream);
+/* All-reduce of a row-parallel projection + the decoder layer's continuation in ONE launch (replaces the all-reduce
+ * followed by sq_add_rmsnorm_f16 / _frag_f16; Engine/Llama_modules.py:282-288,341-346 on a tensor-parallel shard):
+ *   x[r]  <- h(x[r] + sum over ranks of partial[r])        (skip connection, residual stream updated in place)
+ *   out[r] = h(weight * h(x[r] * rsqrt(mean(x[r]^2) + eps)))  (row-major, or the fragment-major operand image: out_frag)
+ * partial = fp32 split-K slabs [splits][rows][hidden] (slab != NULL) or fp16 rows (in_rows).  The reduction is cut along
+ * rows so that the block that gathers a row also normalises it; arithmetic and summation order are those of the
+ * three-launch form, bit for bit.  ceil(rows / world) * hidden must fit a rank's chunk of the workspace.              */
+int sq_allreduce_add_rmsnorm_f16(const void* slab, int splits, const void* in_rows, void* x, const void* weight, void* out,
+                                 int out_frag, int rows, int hidden, float eps, int rank, int world, void* const* ws,
+                                 size_t max_elems, void* stream);
 
 /* ---- f1: RMSNorm folded into the projection that consumes it (small draft models) ------------------------------
  * out = epilogue( (RMSNorm(x) * norm_weight) . w^T ) for m <= 48 rows and k in {256, 512, 768, 1024} (the 68m / 160m drafts): every

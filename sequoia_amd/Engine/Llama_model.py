@@ -274,7 +274,8 @@ class _LlamaForCausalLM:
         if self.ts is not None and os.environ.get("SEQUOIA_TS_EXCLUSIVE", "0") == "1":
             self.ts.make_exclusive()
         self.reduce_fn = reduce_fn                  # TP all-reduce hook (None on one GPU)
-        self.reduce_slabs_fn = None                 # TP: all-reduce straight from split-K partials (xGMI kernel), optional
+        self.reduce_slabs_fn = None
+        self.reduce_norm_fn = None       # (partial, splits, x, weight, out, eps, out_frag): all-reduce + skip + RMSNorm                 # TP: all-reduce straight from split-K partials (xGMI kernel), optional
         self.gather_logits_fn = gather_logits_fn    # TP vocab all-gather hook
 
     def eval(self):

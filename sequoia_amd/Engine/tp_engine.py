@@ -26,6 +26,9 @@ FORCE_HOOKS = os.environ.get("SEQUOIA_TP_FORCE_HOOKS", "0") == "1"
 # all-reduce of the row-parallel projections: "xgmi" = the two-shot kernel over peer-mapped buffers (csrc/allreduce.hip,
 # Engine/xgmi_allreduce.py) with RCCL as the fallback when its setup or self-check fails; "rccl" = torch.distributed only
 ALLREDUCE = os.environ.get("SEQUOIA_TP_ALLREDUCE", "xgmi")
+# "1": the all-reduce of o_proj / down_proj also applies the skip connection and the following RMSNorm (row-aligned two-shot,
+# sq_allreduce_add_rmsnorm_f16) -- two launches per layer fewer; "0": all-reduce, then sq_add_rmsnorm_*.  Same bits either way.
+FUSED_NORM = os.environ.get("SEQUOIA_TP_FUSED_NORM", "1") == "1"
 
 
 class _TPInner(InferenceEngineTG):
@@ -48,6 +51,8 @@ class _TPInner(InferenceEngineTG):
             self.model.gather_logits_fn = self._gather_vocab
             if self.xgmi is not None:
                 self.model.reduce_slabs_fn = self._all_reduce_slabs
+                if FUSED_NORM:
+                    self.model.reduce_norm_fn = self._all_reduce_norm
 
     def _all_reduce(self, x):
         self.collectives += 1
@@ -63,6 +68,13 @@ class _TPInner(InferenceEngineTG):
             return None
         self.collectives += 1
         return self.xgmi.reduce_slabs(slab, splits, rows)
+
+    def _all_reduce_norm(self, partial, splits, x, weight, out, eps, out_frag):
+        """x <- x + all-reduce(partial), out <- RMSNorm(x) * weight in one kernel (row-aligned two-shot); None = does not fit."""
+        if self.xgmi is None or not self.xgmi.fits_rows(x.shape[0], x.shape[1]):
+            return None
+        self.collectives += 1
+        return self.xgmi.reduce_add_rmsnorm(partial, x, weight, out, eps, out_frag, splits=splits)
 
     @property
     def collectives_capturable(self):

@@ -401,6 +401,18 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
             rows = pending[1]
         return ("rows", reduce_fn(rows))
 
+    reduce_norm_fn = getattr(model, "reduce_norm_fn", None) if reduce_fn is not None else None
+
+    def reduce_norm(partial, weight, want_frag):
+        """Tensor-parallel continuation of a row-parallel projection: x += all-reduce(partial); RMSNorm into the next operand.
+        One kernel when the xGMI collectives are up (row-aligned all-reduce that finishes the rows it gathers)."""
+        if reduce_norm_fn is not None:
+            out = torch.empty(fs(q_len, hidden) if want_frag else (q_len, hidden), dtype=dt, device=dev)
+            src, splits = (slab, partial[1]) if partial[0] == "slab" else (partial[1], 0)
+            if reduce_norm_fn(src, splits, x, weight, out, eps, want_frag) is not None:
+                return out
+        return norm_into(reduced(partial), weight, want_frag)
+
     def norm_into(pending, weight, want_frag):
         """Apply the pending branch output (None | ("rows", t) | ("slab", splits)) to the residual stream x,
         then RMSNorm into a row-major or fragment-major buffer."""
@@ -437,7 +449,7 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
             h = torch.empty(fs(q_len, hidden) if want else (q_len, hidden), dtype=dt, device=dev)
             ops.embed_rmsnorm(ids, W.embed, lw.ln1, x, h, eps, out_frag=want)
         else:
-            h = norm_into(pending, lw.ln1, plan["qkv"] is not None)
+            h = reduce_norm(pending, lw.ln1, plan["qkv"] is not None)
         qkv = project("qkv", li, h)
         if qkv[0] == "slab":
             attn = attention_core(None, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
@@ -445,8 +457,7 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
         else:
             attn = attention_core(qkv[1], li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
                                   out_frag=plan["o"] is not None)
-        pending = reduced(project("o", li, attn))
-        h = norm_into(pending, lw.ln2, plan["gate_up"] is not None)
+        h = reduce_norm(project("o", li, attn), lw.ln2, plan["gate_up"] is not None)
         down_ts = plan["down"] is not None
         act = torch.empty(fs(q_len, inter) if down_ts else (q_len, inter), dtype=dt, device=dev)
         if plan["gate_up"] is not None:
@@ -462,8 +473,8 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
                 ops.silu_mul_frag(gu, act, q_len, inter)
             else:
                 ops.silu_mul(gu, act)
-        pending = reduced(project("down", li, act))
-    h = norm_into(pending, W.norm, plan["lm_head"] is not None)
+        pending = project("down", li, act)
+    h = reduce_norm(pending, W.norm, plan["lm_head"] is not None)
     kv_cache.note_written(q_len)
     if plan["lm_head"] is not None:
         tiles, _ = plan["lm_head"]

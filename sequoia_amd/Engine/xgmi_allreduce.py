@@ -145,6 +145,31 @@ class XgmiAllReduce:
         self.calls += 1
         return out
 
+    def fits_rows(self, rows: int, hidden: int) -> bool:
+        """Row-aligned form: a rank's share of the rows must fit its chunk of the staging areas."""
+        chunk_cap = (-(-self.max_elems // self.world) + 7) // 8 * 8
+        return rows > 0 and hidden % 32 == 0 and hidden <= 16384 and -(-rows // self.world) * hidden <= chunk_cap
+
+    def reduce_add_rmsnorm(self, partial, x: torch.Tensor, weight: torch.Tensor, out: torch.Tensor, eps: float,
+                           out_frag: bool, splits: int = 0) -> torch.Tensor:
+        """x <- x + all-reduce(partial); out = RMSNorm(x) * weight (row-major or fragment-major), one launch.
+        partial: fp16 rows [rows, hidden] (splits == 0) or the fp32 split-K slab [splits][rows][hidden]."""
+        rows, hidden = x.shape
+        assert x.dtype == torch.float16 and x.is_contiguous() and weight.dtype == torch.float16 and out.dtype == torch.float16
+        if splits:
+            assert partial.dtype == torch.float32 and partial.numel() >= splits * rows * hidden
+            slab_p, rows_p = partial.data_ptr(), None
+        else:
+            assert partial.dtype == torch.float16 and partial.is_contiguous() and partial.numel() == rows * hidden
+            slab_p, rows_p = None, partial.data_ptr()
+        native.check(self.lib.sq_allreduce_add_rmsnorm_f16(slab_p, int(splits), rows_p, x.data_ptr(), weight.data_ptr(),
+                                                           out.data_ptr(), int(bool(out_frag)), rows, hidden, float(eps),
+                                                           self.rank, self.world, self._table, self.max_elems,
+                                                           torch.cuda.current_stream().cuda_stream),
+                     "sq_allreduce_add_rmsnorm_f16")
+        self.calls += 1
+        return out
+
     def gather_cols(self, slice_: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """[rows, v] per rank -> [rows, world v] on every rank (rank r's columns at [r v, (r + 1) v))."""
         rows, v = slice_.shape

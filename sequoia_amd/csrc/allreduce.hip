@@ -358,3 +358,193 @@ extern "C" int sq_allgather_cols_f16(const void* slice, void* out, int rows, int
     hipLaunchKernelGGL(allgather_cols_kernel, dim3(P.blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, P);
     return sq_check_launch();
 }
+
+// ---- all-reduce + residual add + RMSNorm in one launch -----------------------------------------------------------------------------
+// The tensor-parallel decoder layer continues, after each all-reduce, with x <- x + sum (the skip connection) and
+// h <- RMSNorm(x) * g for the next projection (Engine/Llama_modules.py:282-288,341-346) -- a row-wise pass that needs whole
+// rows.  Here the two-shot all-reduce is cut along ROWS (rank p reduces rows [p rpc, (p + 1) rpc), rpc = ceil(rows / W);
+// block b of every rank owns the rows b, b + B, ... of every chunk in all phases), so that after the all-gather phase a block
+// holds complete rows and finishes them itself: residual add, sum of squares, normalisation, fragment-major (or row-major)
+// image of the next projection's operand.  Per layer two launches (sq_add_rmsnorm_*) fewer.  The arithmetic is that of
+// rmsnorm_kernel<true, .> (fused_ops.hip) to the last bit -- same fp16 roundings, and the sum of squares is accumulated in
+// that kernel's order (256 lanes x strided chunks, 4 wave sums combined by wave_sum_f32_dpp) -- so the fused and the
+// three-launch form of a tensor-parallel forward agree bit for bit (tests/test_xgmi_allreduce_gpu.py).
+struct ArnParams {
+    const float* slab;               // input: fp32 split-K partials [splits][rows][hidden], or
+    int splits;
+    size_t split_stride;
+    const half_t* in_rows;           //        fp16 rows [rows][hidden]
+    half_t* x;                       // residual stream [rows][hidden], updated in place
+    const half_t* g;                 // norm weight [hidden]
+    half_t* out;                     // normalised rows: fragment-major image (frag_mtp > 0) or row-major
+    char* ws[AR_MAX_WORLD];
+    size_t max_elems;
+    int rows, hidden, frag_mtp, rank, world, blocks, rpc;
+    float eps;
+    uint32_t spin_limit;
+};
+
+__device__ __forceinline__ half8 arn_input(const ArnParams& P, size_t e) {       // e: element index, multiple of 8
+    if (!P.slab) return *(const half8*)(P.in_rows + e);
+    const float* sp = P.slab + e;
+    floatx4 a = *(const floatx4*)sp, b = *(const floatx4*)(sp + 4);
+    for (int s = 1; s < P.splits; ++s) {
+        a += *(const floatx4*)(sp + s * P.split_stride);
+        b += *(const floatx4*)(sp + s * P.split_stride + 4);
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = (half_t)a[j]; o[4 + j] = (half_t)b[j]; }
+    return o;
+}
+
+__global__ void __launch_bounds__(AR_THREADS) allreduce_add_rmsnorm_kernel(const ArnParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char arn_lds[];
+    half_t* s_row = (half_t*)arn_lds;                          // [hidden] the summed row x + reduced
+    __shared__ float s_f[4];
+    const int b = blockIdx.x, tid = threadIdx.x, W = P.world, R = P.rank;
+    const ArLayout L = ar_layout(W, P.max_elems);
+    char* mine = P.ws[R];
+    uint32_t* status = (uint32_t*)mine;
+    uint32_t* epochs = (uint32_t*)(mine + 256);
+    __shared__ uint32_t s_epoch;
+    if (tid == 0) s_epoch = epochs[b] + 1;
+    __syncthreads();
+    const uint32_t epoch = s_epoch;
+    const int vec = P.hidden >> 3, rpc = P.rpc;
+
+    // ---- phase 1: my partial of the rows rank p reduces -> peer p's area A, slot R ---------------------------------------
+    for (int d = 1; d < W; ++d) {
+        const int p = (R + d) % W;
+        half_t* dst = (half_t*)(P.ws[p] + L.area_a) + (size_t)R * L.chunk_cap;
+        for (int lr = b; lr < rpc; lr += P.blocks) {
+            const int row = p * rpc + lr;
+            if (row >= P.rows) break;
+            for (int v = tid; v < vec; v += AR_THREADS)
+                *(half8*)(dst + (size_t)lr * P.hidden + v * 8) = arn_input(P, (size_t)row * P.hidden + v * 8);
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < W && tid != R)
+        ar_flag_store((uint32_t*)(P.ws[tid] + L.flags1) + ((size_t)R * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch);
+
+    // ---- phase 2: reduce my rows (rank order, fp32, one rounding), publish them to every rank's area B (mine included) -----
+    if (tid < W && tid != R) {
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags1) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit))
+            atomicOr(status, 1u);
+    }
+    __syncthreads();
+    {
+        const half_t* a = (const half_t*)(mine + L.area_a);
+        for (int lr = b; lr < rpc; lr += P.blocks) {
+            const int row = R * rpc + lr;
+            if (row >= P.rows) break;
+            for (int v = tid; v < vec; v += AR_THREADS) {
+                float acc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+                for (int p = 0; p < W; ++p) {
+                    const half8 xin = p == R ? arn_input(P, (size_t)row * P.hidden + v * 8)
+                                             : __builtin_nontemporal_load((const half8*)(a + (size_t)p * L.chunk_cap + (size_t)lr * P.hidden + v * 8));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += (float)xin[j];
+                }
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+                for (int p = 0; p < W; ++p)
+                    *(half8*)((half_t*)(P.ws[p] + L.area_b) + (size_t)R * L.chunk_cap + (size_t)lr * P.hidden + v * 8) = o;
+            }
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < W && tid != R)
+        ar_flag_store((uint32_t*)(P.ws[tid] + L.flags2) + ((size_t)R * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch);
+
+    // ---- phase 3: every chunk's rows of this block are complete here: residual add + RMSNorm --------------------------------
+    if (tid < W && tid != R) {
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit))
+            atomicOr(status, 2u);
+    }
+    __syncthreads();
+    const half_t* bsrc = (const half_t*)(mine + L.area_b);
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int p = 0; p < W; ++p) {
+        for (int lr = b; lr < rpc; lr += P.blocks) {
+            const int row = p * rpc + lr;
+            if (row >= P.rows) break;
+            // x <- h(reduced + x)  (fp16 add, the decoder layer's skip connection), staged in LDS
+            for (int v = tid; v < vec; v += AR_THREADS) {
+                const half8 o = __builtin_nontemporal_load((const half8*)(bsrc + (size_t)p * L.chunk_cap + (size_t)lr * P.hidden + v * 8));
+                const half8 r = *(const half8*)(P.x + (size_t)row * P.hidden + v * 8);
+                half8 s;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] = (half_t)((float)o[j] + (float)r[j]);
+                *(half8*)(P.x + (size_t)row * P.hidden + v * 8) = s;
+                *(half8*)(s_row + v * 8) = s;
+            }
+            __syncthreads();
+            // sum of squares in rmsnorm_kernel's order: 256 lanes, lane t takes chunks t, t + 256, ...; 4 wave sums, then one more
+            float ss = 0.f;
+            if (tid < 256) {
+                for (int c = tid; c < vec; c += 256) {
+                    const half8 s = *(const half8*)(s_row + c * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += (float)s[j] * (float)s[j];
+                }
+            }
+            const float wsum = wave_sum_f32_dpp(ss);
+            if (wave < 4 && lane == 0) s_f[wave] = wsum;
+            __syncthreads();
+            float r4 = (lane < 4) ? s_f[lane] : 0.0f;
+            const float tot = wave_sum_f32_dpp(r4);
+            const float inv = rsqrtf(tot / (float)P.hidden + P.eps);
+            for (int c = tid; c < vec; c += AR_THREADS) {
+                const half8 s = *(const half8*)(s_row + c * 8);
+                const half8 wv = *(const half8*)(P.g + c * 8);
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const half_t nrm = (half_t)((float)s[j] * inv);
+                    o[j] = (half_t)((float)wv[j] * (float)nrm);
+                }
+                *(half8*)(P.out + (P.frag_mtp ? frag_chunk_offset((size_t)row, c, P.frag_mtp) : (size_t)row * P.hidden + c * 8)) = o;
+            }
+            __syncthreads();                                   // s_row / s_f are reused by the next row
+        }
+    }
+    if (tid == 0) epochs[b] = epoch;
+}
+
+extern "C" int sq_allreduce_add_rmsnorm_f16(const void* slab, int splits, const void* in_rows, void* x, const void* weight, void* out,
+                                            int out_frag, int rows, int hidden, float eps, int rank, int world, void* const* ws,
+                                            size_t max_elems, void* stream) {
+    if ((!slab && !in_rows) || !x || !weight || !out || !ws || rows <= 0 || hidden <= 0) return SQ_EINVAL;
+    if (world < 2 || world > AR_MAX_WORLD || rank < 0 || rank >= world) return SQ_EINVAL;
+    if (slab && (splits < 1 || ((uintptr_t)slab & 15))) return SQ_EINVAL;
+    const ArLayout L = ar_layout(world, max_elems);
+    const int rpc = (rows + world - 1) / world;
+    if ((hidden & 7) || (out_frag && (hidden & 31)) || hidden > 16384 || (size_t)rpc * hidden > L.chunk_cap ||
+        ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)weight & 15) || (in_rows && ((uintptr_t)in_rows & 15)))
+        return SQ_EUNSUPPORTED;
+    ArnParams P;
+    P.slab = (const float*)slab; P.splits = slab ? splits : 0; P.split_stride = (size_t)rows * hidden;
+    P.in_rows = (const half_t*)in_rows; P.x = (half_t*)x; P.g = (const half_t*)weight; P.out = (half_t*)out;
+    P.max_elems = max_elems; P.rows = rows; P.hidden = hidden; P.frag_mtp = out_frag ? (rows + 15) / 16 : 0;
+    P.rank = rank; P.world = world; P.rpc = rpc; P.eps = eps;
+    P.blocks = rpc < AR_MAX_BLOCKS ? rpc : AR_MAX_BLOCKS;
+    for (int i = 0; i < AR_MAX_WORLD; ++i) P.ws[i] = i < world ? (char*)ws[i] : nullptr;
+    for (int i = 0; i < world; ++i)
+        if (!P.ws[i]) return SQ_EINVAL;
+    static uint32_t spin_limit = 0;
+    if (!spin_limit) {
+        const char* e = getenv("SEQUOIA_AR_SPIN_LIMIT");
+        const long v = e ? atol(e) : 0;
+        spin_limit = v > 0 ? (uint32_t)v : AR_SPIN_LIMIT;
+    }
+    P.spin_limit = spin_limit;
+    hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel, dim3(P.blocks), dim3(AR_THREADS), (size_t)hidden * sizeof(half_t), (hipStream_t)stream, P);
+    return sq_check_launch();
+}

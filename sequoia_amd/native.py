@@ -81,6 +81,7 @@ PROTOTYPES = {
     "sq_allreduce_sum_f16": (_i, [_vp, C.c_size_t, _i, _i, C.POINTER(_vp), C.c_size_t, _i, _vp]),
     "sq_allreduce_sum_slabs_f16": (_i, [_vp, _i, _vp, C.c_size_t, _i, _i, C.POINTER(_vp), C.c_size_t, _i, _vp]),
     "sq_allgather_cols_f16": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(_vp), C.c_size_t, C.c_size_t, _vp]),
+    "sq_allreduce_add_rmsnorm_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _i, C.POINTER(_vp), C.c_size_t, _vp]),
 }
 
 _lib = None

@@ -79,6 +79,42 @@ def _ar_worker(rank, world, port, out_dir):
         ar.reduce_slabs(slab.reshape(-1), splits, out)
         torch.cuda.synchronize()
         assert ar.status() == 0 and torch.equal(out, ref), f"slab all-reduce {rows} x {hid} x {splits}"
+    # 1d. all-reduce + skip connection + RMSNorm in one launch (row-aligned two-shot) == all-reduce, then sq_add_rmsnorm_*:
+    #     same bits in the residual stream and in the normalised operand (row-major and fragment-major), from fp16 rows and
+    #     from split-K slabs, for row counts that do not divide by the world (ranks without rows included), interleaved
+    #     with plain all-reduces (shared epochs) and called back to back
+    from sequoia_amd.ops import HipOps
+    hip = HipOps()
+    for i, (rows, hid, splits, frag) in enumerate([(129, 8192, 0, True), (129, 8192, 2, True), (1, 4096, 0, True), (3, 768, 3, False),
+                                                    (34, 768, 0, True), (144, 8192, 2, False), (19, 5120, 0, True), (5, 8192, 4, True)]):
+        gen.manual_seed(1300 + 11 * i + rank)
+        if splits:
+            part = torch.randn(splits, rows * hid, generator=gen).to(dev)
+            acc = part[0].clone()
+            for sidx in range(1, splits):
+                acc += part[sidx]
+            mine = acc.half().reshape(rows, hid)
+        else:
+            part = torch.randn(rows, hid, generator=gen).half().to(dev)
+            mine = part.clone()
+        gen.manual_seed(1300 + 11 * i)                                   # replicated: residual stream and norm weight
+        x0 = torch.randn(rows, hid, generator=gen).half().to(dev)
+        g = (1.0 + 0.1 * torch.randn(hid, generator=gen)).half().to(dev)
+        red = ar(mine.clone().reshape(-1)).reshape(rows, hid)
+        x_ref = x0.clone()
+        o_ref = torch.zeros(hip.frag_shape(rows, hid) if frag else (rows, hid), dtype=torch.float16, device=dev)
+        (hip.add_rmsnorm_frag if frag else hip.add_rmsnorm)(red, x_ref, x_ref, g, o_ref, 1e-5)
+        for rep in range(2):
+            x = x0.clone()
+            out = torch.zeros_like(o_ref)
+            assert ar.fits_rows(rows, hid)
+            ar.reduce_add_rmsnorm(part.reshape(-1) if splits else part, x, g, out, 1e-5, frag, splits=splits)
+            ar(torch.ones(64, dtype=torch.float16, device=dev))
+            torch.cuda.synchronize()
+            assert ar.status() == 0
+            assert torch.equal(x, x_ref), f"residual stream {rows} x {hid} splits {splits}"
+            assert torch.equal(out, o_ref), f"normalised rows {rows} x {hid} splits {splits} frag {frag}"
+    assert not ar.fits_rows(145 * world, 8192)
     # 2. a burst of back-to-back calls without host synchronisation, arrival skewed (one rank is kept busy / asleep):
     #    call k + 1 of the fast rank must not disturb call k of the slow one (per-block epochs, areas reused every call)
     n = 129 * 8192
@@ -175,14 +211,16 @@ def test_missing_peer_times_out_instead_of_hanging(tmp_path, monkeypatch):
     assert int(np.load(tmp_path / "lonely.npy")[0]) & 1 == 1
 
 
-@pytest.mark.parametrize("name,world", [("E_64x2", 2), ("E_70b_w2", 2), ("E_64x2", 4), ("demo4", 4)])
-def test_tp_on_the_xgmi_allreduce_matches_reference_trace(name, world, tmp_path, monkeypatch):
+@pytest.mark.parametrize("name,world,fused_norm", [("E_64x2", 2, "1"), ("E_70b_w2", 2, "1"), ("E_64x2", 4, "1"), ("demo4", 4, "1"),
+                                                   ("E_64x2", 2, "0")])
+def test_tp_on_the_xgmi_allreduce_matches_reference_trace(name, world, fused_norm, tmp_path, monkeypatch):
     """The tensor-parallel target (KV-head split, vocabulary-parallel lm_head) with its row-parallel projections reduced
     by the xGMI kernel: every step of the reference's trace on both ranks (tests/test_tp_gloo_cpu.py::_worker asserts
     identical decisions on both ranks)."""
     from test_tp_gloo_cpu import _worker
     monkeypatch.setenv("SEQUOIA_TP_ALLREDUCE", "xgmi")
     monkeypatch.setenv("SEQUOIA_TP_REQUIRE_XGMI", "1")
+    monkeypatch.setenv("SEQUOIA_TP_FUSED_NORM", fused_norm)      # "1": all-reduce + skip + RMSNorm in one kernel; "0": three launches
     port = 36300 + (os.getpid() % 1500) + world
     mp.spawn(_worker, args=(world, port, name, str(tmp_path), "cuda:0"), nprocs=world, join=True)
     from conftest import load_trace
