@@ -360,6 +360,14 @@ int sq_linear_ts_prefetch(const void* w_frag, int n_out, int k, int silu, int ti
  * out = RMSNorm(x_out) * weight, row-major or (out_frag) fragment-major.  ids: int64 [rows], clamped to [0, vocab).   */
 int sq_embed_rmsnorm_f16(const int64_t* d_ids, const void* embed, int vocab, const void* weight, void* x_out, void* out,
                          int out_frag, int rows, int hidden, float eps, void* stream);
+/* The same pass with the forward's inputs staged in it (device-driven speculation step): sq_stage_tree_inputs's work --
+ * ids / storage ids / position ids of the `rows` queries at slots [gt + rel_slot0, ...), the {q_slot0, gt, kv_len}
+ * context block, the step block's advance -- done by the workgroups that then look up and normalise the rows, so a
+ * forward starts with one launch instead of two (same arguments and meaning as sq_stage_tree_inputs + the call above). */
+int sq_embed_stage_rmsnorm_f16(int64_t* dst_ids, int64_t* dst_pos, int64_t* dst_storage, int32_t* d_ctx,
+                               const int64_t* tokens, const int32_t* d_depth, int n_tree, int rel_slot0, int rel_kv_len,
+                               int32_t* d_step, int advance, const void* embed, int vocab, const void* weight, void* x_out,
+                               void* out, int out_frag, int rows, int hidden, float eps, void* stream);
 
 /* Residual add + RMSNorm fed by a split-K linear layer: x = h(sum_s slab[s]) (the layer's fp16 output),
  * then exactly sq_add_rmsnorm_f16: sum_out = x + residual (fp16), out = RMSNorm(sum_out) * weight

@@ -319,6 +319,8 @@ class _LlamaForCausalLM:
         # tree forwards (and tensor-parallel shards: the hooks are applied inside forward_ts) on the tall-skinny path
         if self.ts is not None and q_len <= TS_MAX_ROWS:
             return forward_ts(self, self.ts, input_ids[0], q_len, pos, storage_ids, dense, tree, kv_cache)
+        if tree is not None and tree.stage is not None:
+            ops.stage_tree_inputs(*tree.stage)         # device-driven step on the general path: staging is its own launch
         if self.ts is not None and self.ts.exclusive:
             return self._forward_chunked(input_ids, q_len, pos, storage_ids, dense, tree, kv_cache)
         x = F.embedding(input_ids[0], W.embed)                      # [q, hidden]

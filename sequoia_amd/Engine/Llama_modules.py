@@ -41,6 +41,9 @@ class TreeContext:
     kv_len: int
     ctx: torch.Tensor | None = None
     contiguous_slots: bool = False     # storage_ids == q_slot0 + arange(q_len): enables the fused RoPE+attention launch
+    # device-driven step (Tree/step_graph.py): the arguments of ops.stage_tree_inputs for this forward's static input buffers;
+    # a forward on the tall-skinny path stages its inputs inside its first launch (ops.embed_stage_rmsnorm)
+    stage: tuple | None = None
 
 
 @dataclass

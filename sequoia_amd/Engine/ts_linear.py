@@ -369,7 +369,10 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
     Returns logits [1, q, V].  Tensor-parallel shards (model.reduce_fn set): the partial output of the row-parallel
     projections (o_proj, down_proj) is reduced across ranks before the residual add; the vocabulary-parallel logits
     are gathered at the end (model.gather_logits_fn)."""
+    stage = tree.stage if tree is not None else None
     if small_fused_ok(model, ts, q_len):
+        if stage is not None:
+            get_ops().stage_tree_inputs(*stage)
         return forward_small_fused(model, ts, ids, q_len, pos, storage_ids, dense, tree, kv_cache)
     from .Llama_modules import attention_core
     ops = get_ops()
@@ -447,7 +450,10 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
         if li == 0:                                              # embedding lookup + first norm, one launch
             want = plan["qkv"] is not None
             h = torch.empty(fs(q_len, hidden) if want else (q_len, hidden), dtype=dt, device=dev)
-            ops.embed_rmsnorm(ids, W.embed, lw.ln1, x, h, eps, out_frag=want)
+            if stage is not None:      # device-driven step: ids / positions / slots / context staged by the same launch
+                ops.embed_stage_rmsnorm(stage, W.embed, lw.ln1, x, h, eps, out_frag=want)
+            else:
+                ops.embed_rmsnorm(ids, W.embed, lw.ln1, x, h, eps, out_frag=want)
         else:
             h = reduce_norm(pending, lw.ln1, plan["qkv"] is not None)
         qkv = project("qkv", li, h)

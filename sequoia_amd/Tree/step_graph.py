@@ -11,6 +11,8 @@ per-prompt tree objects of the harness: a new tree adopts them (per-prompt const
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ..Engine.Llama_modules import TreeContext
@@ -20,6 +22,9 @@ from ..ops import get_ops
 from .Tree import _content_key
 
 N_BONUS = 1024
+# "1": a forward on the tall-skinny path stages its own inputs in its first launch (sq_embed_stage_rmsnorm_f16) -- 7 launches per
+# step fewer; "0": sq_stage_tree_inputs in front of every forward
+FUSE_STAGE = os.environ.get("SEQUOIA_FUSE_STAGE", "1") == "1"
 
 
 class _Fwd:
@@ -105,12 +110,11 @@ class StepState:
             else:
                 ops.topk(self.draft_logits, lv["row_ids"], lv["k"], out, branch=lv["branch"], out_off=lv["out_off"],
                          out_base=gt_dev)
-            ops.stage_tree_inputs(f.ids, f.pos, f.sto, f.ctx, self.tokens, depth, n, first - 1, first - 1 + lv["total"],
-                                  self.step)
+            self._stage(f, first - 1, first - 1 + lv["total"])
             logits = dm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None, tree=f.tree)
             self._adopt_rows(logits[0], first, lv["total"])
         f = self.fwd_target
-        ops.stage_tree_inputs(f.ids, f.pos, f.sto, f.ctx, self.tokens, depth, n, -1, n - 1, self.step)
+        self._stage(f, -1, n - 1)
         target_logits = tm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None,
                                      tree=f.tree)[0]
         self.target_logits = target_logits
@@ -129,9 +133,20 @@ class StepState:
             kv = eng.kv_cache
             ops.kv_compact(kv.k_cache, kv.v_cache, slots, count, g["max_depth"], 0, 0, dst_offset_dev=gt_dev)
         f = self.fwd_one                                   # next root: the bonus token at slot new_gt - 1
-        ops.stage_tree_inputs(f.ids, f.pos, f.sto, f.ctx, self.tokens, depth, n, -1, 0, self.step, advance=True)
+        self._stage(f, -1, 0, advance=True)
         logits = dm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None, tree=f.tree)
         self._adopt_rows(logits[0], 0, 1)
+
+    def _stage(self, f, rel_slot0, rel_kv_len, advance=False):
+        """Inputs of the forward that follows: handed to the model through the forward's TreeContext -- on the tall-skinny
+        path (CUDA) the forward's first launch stages them itself (ops.embed_stage_rmsnorm), elsewhere
+        ops.stage_tree_inputs runs here as a launch of its own."""
+        args = (f.ids, f.pos, f.sto, f.ctx, self.tokens, self.gdev["depth32"], self.n, rel_slot0, rel_kv_len, self.step, advance)
+        if self.cuda and FUSE_STAGE:
+            f.tree.stage = args                      # Engine/Llama_model.py::forward falls back to the separate launch
+        else:
+            f.tree.stage = None
+            self.ops.stage_tree_inputs(*args)
 
     def _adopt_rows(self, rows, first, total):
         """draft_logits[first:first+total] = the forward's last `total` rows (Tree/SpecTree.py:121,279), with the

@@ -77,11 +77,10 @@ __device__ __forceinline__ bool ar_flag_wait(const uint32_t* p, uint32_t want, u
 __device__ __forceinline__ half8 ar_input(const ArParams& P, size_t g) {
     if (!P.slab) return *(const half8*)(P.data + g * 8);
     const float* sp = P.slab + g * 8;
-    floatx4 a = *(const floatx4*)sp, b = *(const floatx4*)(sp + 4);
-    for (int s = 1; s < P.splits; ++s) {
-        a += *(const floatx4*)(sp + s * P.split_stride);
-        b += *(const floatx4*)(sp + s * P.split_stride + 4);
-    }
+    const float* const spp[1] = {sp};
+    floatx4 av[1], bv[1];
+    slab_sum8<1>(spp, P.splits, P.split_stride, av, bv);
+    const floatx4 a = av[0], b = bv[0];
     half8 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[j] = (half_t)a[j]; o[4 + j] = (half_t)b[j]; }
@@ -387,11 +386,10 @@ struct ArnParams {
 __device__ __forceinline__ half8 arn_input(const ArnParams& P, size_t e) {       // e: element index, multiple of 8
     if (!P.slab) return *(const half8*)(P.in_rows + e);
     const float* sp = P.slab + e;
-    floatx4 a = *(const floatx4*)sp, b = *(const floatx4*)(sp + 4);
-    for (int s = 1; s < P.splits; ++s) {
-        a += *(const floatx4*)(sp + s * P.split_stride);
-        b += *(const floatx4*)(sp + s * P.split_stride + 4);
-    }
+    const float* const spp[1] = {sp};
+    floatx4 av[1], bv[1];
+    slab_sum8<1>(spp, P.splits, P.split_stride, av, bv);
+    const floatx4 a = av[0], b = bv[0];
     half8 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[j] = (half_t)a[j]; o[4 + j] = (half_t)b[j]; }

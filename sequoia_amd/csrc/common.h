@@ -30,9 +30,9 @@ static inline int sq_check_launch() {
 
 // fp16 <-> sortable unsigned 16-bit (larger float => larger unsigned; NaN largest, like torch.topk)
 __device__ __forceinline__ uint32_t f16_to_ordered(half_t x) {
-    uint16_t b = __builtin_bit_cast(uint16_t, x);
-    if ((b & 0x7fffu) > 0x7c00u) return 0xffffu;            // NaN
-    return (b & 0x8000u) ? (uint16_t)~b : (uint16_t)(b | 0x8000u);
+    const uint16_t b = __builtin_bit_cast(uint16_t, x);
+    const uint32_t o = (b & 0x8000u) ? (uint16_t)~b : (uint16_t)(b | 0x8000u);
+    return ((b & 0x7fffu) > 0x7c00u) ? 0xffffu : o;         // NaN (selects only: callers unroll this per element)
 }
 
 // Correctly rounded fp32 division for operands whose quotient cannot over/underflow (both here are
@@ -42,9 +42,11 @@ __device__ __forceinline__ float div_rn(float a, float b) {
     const float r0 = __builtin_amdgcn_rcpf(b);
     const float r = __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);   // refine 1/b to <= 0.5 ulp-ish
     const float q0 = a * r;
-    if (!(__builtin_fabsf(q0) < INFINITY)) return q0;   // +-inf / NaN numerators propagate like IEEE division
     const float e = __builtin_fmaf(-q0, b, a);
-    return __builtin_fmaf(e, r, q0);
+    const float q1 = __builtin_fmaf(e, r, q0);
+    // +-inf / NaN numerators propagate like IEEE division (a select, not an early return: callers unroll this over 8-32
+    // elements and an early return became one exec-mask branch per element)
+    return (__builtin_fabsf(q0) < INFINITY) ? q1 : q0;
 }
 
 // exp / log on the hardware transcendental units (v_exp_f32 / v_log_f32 are base-2, 1 ulp) with the
@@ -67,9 +69,9 @@ __device__ __forceinline__ float log_fast(float u) {           // u >= 0
     return logf(u);
 #else
     const float l2 = __builtin_amdgcn_logf(u);                // log2(u); log2(0) = -inf
-    if (!(l2 > -INFINITY)) return l2;
     const float hi = l2 * 6.93147182e-01f;
-    return __builtin_fmaf(l2, -1.90465421e-09f, hi + __builtin_fmaf(l2, 6.93147182e-01f, -hi));
+    const float r = __builtin_fmaf(l2, -1.90465421e-09f, hi + __builtin_fmaf(l2, 6.93147182e-01f, -hi));
+    return (l2 > -INFINITY) ? r : l2;                         // a select: no branch per element in unrolled callers
 #endif
 }
 
@@ -185,6 +187,46 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v
     r = wave_max_u64(r);
     __syncthreads();
     return r;
+}
+
+// Sum of `splits` fp32 split-K partials (csrc/ts_linear.hip slabs) of 8 consecutive elements at NP places: ((p0 + p1) + p2)
+// + ... in split order.  Up to 4 splits every load is issued before the first add: a run-time loop `a += load` waits for
+// each split's data before it issues the next load -- one memory round trip PER SPLIT in consumers that are nothing but
+// latency (norm, RoPE, SwiGLU, all-reduce input).  lo[i] / hi[i]: elements 0-3 / 4-7 at sp[i].
+template <int S, int NP>
+__device__ __forceinline__ void slab_sum8_n(const float* const (&sp)[NP], size_t stride, floatx4 (&lo)[NP], floatx4 (&hi)[NP]) {
+    floatx4 av[NP][S], bv[NP][S];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            av[i][s] = *(const floatx4*)(sp[i] + s * stride);
+            bv[i][s] = *(const floatx4*)(sp[i] + s * stride + 4);
+        }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        lo[i] = av[i][0]; hi[i] = bv[i][0];
+#pragma unroll
+        for (int s = 1; s < S; ++s) { lo[i] += av[i][s]; hi[i] += bv[i][s]; }
+    }
+}
+template <int NP>
+__device__ __forceinline__ void slab_sum8(const float* const (&sp)[NP], int splits, size_t stride, floatx4 (&lo)[NP],
+                                          floatx4 (&hi)[NP]) {
+    switch (splits) {                                       // wave-uniform
+    case 1: slab_sum8_n<1, NP>(sp, stride, lo, hi); break;
+    case 2: slab_sum8_n<2, NP>(sp, stride, lo, hi); break;
+    case 3: slab_sum8_n<3, NP>(sp, stride, lo, hi); break;
+    case 4: slab_sum8_n<4, NP>(sp, stride, lo, hi); break;
+    default:
+        slab_sum8_n<4, NP>(sp, stride, lo, hi);
+        for (int s = 4; s < splits; ++s)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                lo[i] += *(const floatx4*)(sp[i] + s * stride);
+                hi[i] += *(const floatx4*)(sp[i] + s * stride + 4);
+            }
+    }
 }
 
 // Tree-causal visibility rule shared by the dense-mask writer and the attention kernel

@@ -98,14 +98,45 @@ extern "C" int sq_add_rmsnorm_frag_f16(const void* x, const void* residual, void
 // First norm of a forward fused with the embedding lookup (Engine/Llama_model.py:151 `embed_tokens(input_ids)` +
 // the first decoder layer's input_layernorm): row r of the residual stream is embed[ids[r]]; it is written out (the
 // residual stream) and normalised in the same pass, row-major or fragment-major.  Same arithmetic as rmsnorm_kernel.
-template <int THREADS, int CPT>
+// STAGE: the forward's inputs are staged here as well (what stage_tree_inputs_kernel does in a launch of its own, csrc/kv_ops.hip:
+// the device-driven speculation step): row i is the token at slot gt + rel_slot0 + i of the tree's token buffer, gt from the
+// device step block; its id / storage id / position id and the {q_slot0, gt, kv_len} context block are written for the
+// kernels that follow (RoPE, attention), the step block advances when asked.  All of it is wave-uniform scalar work in
+// front of the embedding row's load -- one launch per forward fewer (7 per speculation step).
+struct StageArgs {
+    int64_t* dst_ids; int64_t* dst_pos; int64_t* dst_sto; int32_t* ctx;
+    const int64_t* tokens; const int32_t* depth; int32_t* d_step;
+    int n_tree, rel_slot0, rel_kv_len, advance;
+};
+template <int THREADS, int CPT, bool STAGE>
 __global__ void __launch_bounds__(THREADS)
 embed_rmsnorm_kernel(const int64_t* __restrict__ ids, const half_t* __restrict__ embed, int vocab,
                      const half_t* __restrict__ w, half_t* __restrict__ x_out, half_t* __restrict__ out, int hidden,
-                     float eps, int frag_mtp) {
+                     float eps, int frag_mtp, const StageArgs sa) {
     __shared__ float s_f[THREADS / 64];
     const size_t row = blockIdx.x;
-    int64_t id = ids[row];
+    int64_t id;
+    if (STAGE) {
+        const int gt = sa.advance ? sa.d_step[SQ_STEP_NEXT_GT] : sa.d_step[SQ_STEP_GT];
+        const int q_slot0 = gt + sa.rel_slot0;
+        const int slot = q_slot0 + (int)row;
+        const int t = slot - (gt - 1);
+        id = sa.tokens[slot];
+        if (threadIdx.x == 0) {
+            sa.dst_ids[row] = id;
+            sa.dst_sto[row] = slot;
+            sa.dst_pos[row] = (t >= 0 && t < sa.n_tree) ? (int64_t)sa.depth[t] + gt - 1 : (int64_t)slot;
+        }
+        if (row == 0) {
+            if (threadIdx.x < 3) sa.ctx[threadIdx.x] = threadIdx.x == 0 ? q_slot0 : (threadIdx.x == 1 ? gt : gt + sa.rel_kv_len);
+            if (sa.advance && threadIdx.x == 0) {           // (the other rows read NEXT_GT, nobody else touches INDEX)
+                sa.d_step[SQ_STEP_GT] = gt;
+                sa.d_step[SQ_STEP_INDEX] = sa.d_step[SQ_STEP_INDEX] + 1;
+            }
+        }
+    } else {
+        id = ids[row];
+    }
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const half_t* src = embed + (size_t)id * hidden;
     const int chunks = hidden >> 3;
@@ -139,17 +170,18 @@ embed_rmsnorm_kernel(const int64_t* __restrict__ ids, const half_t* __restrict__
     }
 }
 
-extern "C" int sq_embed_rmsnorm_f16(const int64_t* d_ids, const void* embed, int vocab, const void* weight, void* x_out,
-                                    void* out, int out_frag, int rows, int hidden, float eps, void* stream) {
-    if (!d_ids || !embed || !weight || !x_out || !out || rows < 0 || hidden <= 0 || vocab <= 0) return SQ_EINVAL;
+template <bool STAGE>
+static int embed_launch(const int64_t* d_ids, const void* embed, int vocab, const void* weight, void* x_out, void* out,
+                        int out_frag, int rows, int hidden, float eps, const StageArgs& sa, void* stream) {
+    if (!embed || !weight || !x_out || !out || rows < 0 || hidden <= 0 || vocab <= 0) return SQ_EINVAL;
     if ((hidden & 7) || (out_frag && (hidden & 31)) || hidden > 8 * 1024 * 4) return SQ_EUNSUPPORTED;
     if (rows == 0) return SQ_OK;
     const int chunks = hidden >> 3;
     const int mtp = out_frag ? (rows + 15) / 16 : 0;
     hipStream_t st = (hipStream_t)stream;
 #define SQ_EMB(T_, C_)                                                                                             \
-    hipLaunchKernelGGL((embed_rmsnorm_kernel<T_, C_>), dim3(rows), dim3(T_), 0, st, d_ids, (const half_t*)embed, vocab,   \
-                       (const half_t*)weight, (half_t*)x_out, (half_t*)out, hidden, eps, mtp)
+    hipLaunchKernelGGL((embed_rmsnorm_kernel<T_, C_, STAGE>), dim3(rows), dim3(T_), 0, st, d_ids, (const half_t*)embed,  \
+                       vocab, (const half_t*)weight, (half_t*)x_out, (half_t*)out, hidden, eps, mtp, sa)
     if (chunks <= 256) SQ_EMB(256, 1);
     else if (chunks <= 512) SQ_EMB(512, 1);
     else if (chunks <= 1024) SQ_EMB(1024, 1);
@@ -157,6 +189,26 @@ extern "C" int sq_embed_rmsnorm_f16(const int64_t* d_ids, const void* embed, int
     else SQ_EMB(1024, 4);
 #undef SQ_EMB
     return sq_check_launch();
+}
+
+extern "C" int sq_embed_rmsnorm_f16(const int64_t* d_ids, const void* embed, int vocab, const void* weight, void* x_out,
+                                    void* out, int out_frag, int rows, int hidden, float eps, void* stream) {
+    if (!d_ids) return SQ_EINVAL;
+    return embed_launch<false>(d_ids, embed, vocab, weight, x_out, out, out_frag, rows, hidden, eps, StageArgs{}, stream);
+}
+
+extern "C" int sq_embed_stage_rmsnorm_f16(int64_t* dst_ids, int64_t* dst_pos, int64_t* dst_storage, int32_t* d_ctx,
+                                          const int64_t* tokens, const int32_t* d_depth, int n_tree, int rel_slot0,
+                                          int rel_kv_len, int32_t* d_step, int advance, const void* embed, int vocab,
+                                          const void* weight, void* x_out, void* out, int out_frag, int rows, int hidden,
+                                          float eps, void* stream) {
+    if (!dst_ids || !dst_pos || !dst_storage || !d_ctx || !tokens || !d_depth || !d_step) return SQ_EINVAL;
+    if (rows <= 0 || n_tree <= 0 || n_tree > SQ_MAX_TREE) return SQ_EINVAL;
+    StageArgs sa;
+    sa.dst_ids = dst_ids; sa.dst_pos = dst_pos; sa.dst_sto = dst_storage; sa.ctx = d_ctx; sa.tokens = tokens;
+    sa.depth = d_depth; sa.d_step = d_step; sa.n_tree = n_tree; sa.rel_slot0 = rel_slot0; sa.rel_kv_len = rel_kv_len;
+    sa.advance = advance ? 1 : 0;
+    return embed_launch<true>(nullptr, embed, vocab, weight, x_out, out, out_frag, rows, hidden, eps, sa, stream);
 }
 
 // Same as rmsnorm_kernel<true>, with x arriving as `splits` fp32 partial products of a split-K linear layer
@@ -179,18 +231,15 @@ rmsnorm_slabs_kernel(const float* __restrict__ slab, int splits, size_t split_st
     for (int i = 0; i < CPT; ++i) {
         const int c = threadIdx.x + i * THREADS;
         if (c < chunks) {
-            const float* sp = slab + row * hidden + c * 8;
-            floatx4 a = *(const floatx4*)sp, b = *(const floatx4*)(sp + 4);
-            for (int s = 1; s < splits; ++s) {
-                a += *(const floatx4*)(sp + s * split_stride);
-                b += *(const floatx4*)(sp + s * split_stride + 4);
-            }
             const half8 r = *(const half8*)(res + row * hidden + c * 8);
             if (NORM) wv[i] = *(const half8*)(w + c * 8);
+            const float* const sp[1] = {slab + row * hidden + c * 8};
+            floatx4 a[1], b[1];
+            slab_sum8<1>(sp, splits, split_stride, a, b);      // all partials in flight together with r and wv
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[i][j] = (half_t)((float)(half_t)a[j] + (float)r[j]);
-                v[i][4 + j] = (half_t)((float)(half_t)b[j] + (float)r[4 + j]);
+                v[i][j] = (half_t)((float)(half_t)a[0][j] + (float)r[j]);
+                v[i][4 + j] = (half_t)((float)(half_t)b[0][j] + (float)r[4 + j]);
             }
             *(half8*)(sum_out + row * hidden + c * 8) = v[i];
 #pragma unroll
@@ -303,11 +352,10 @@ silu_mul_slabs_kernel(const float* __restrict__ slab, int splits, size_t split_s
     if (c * 8 >= inter) return;
     const float* gp = slab + row * 2 * inter + c * 8;
     const float* up = gp + inter;
-    floatx4 g0 = *(const floatx4*)gp, g1 = *(const floatx4*)(gp + 4), u0 = *(const floatx4*)up, u1 = *(const floatx4*)(up + 4);
-    for (int s = 1; s < splits; ++s) {
-        g0 += *(const floatx4*)(gp + s * split_stride); g1 += *(const floatx4*)(gp + s * split_stride + 4);
-        u0 += *(const floatx4*)(up + s * split_stride); u1 += *(const floatx4*)(up + s * split_stride + 4);
-    }
+    const float* const sp[2] = {gp, up};
+    floatx4 lo[2], hi[2];
+    slab_sum8<2>(sp, splits, split_stride, lo, hi);
+    const floatx4 g0 = lo[0], g1 = hi[0], u0 = lo[1], u1 = hi[1];
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

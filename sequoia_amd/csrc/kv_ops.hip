@@ -246,19 +246,19 @@ extern "C" int sq_kv_clear_f16(void* k_cache, void* v_cache, int n_layers, int h
 // SLAB: the packed q | k | v rows arrive as the split-K partials of the tall-skinny projection (fp32 [splits][q_len][stride],
 // csrc/ts_linear.hip): a value is the sum of its partials in split order, rounded to fp16 -- what the projection itself
 // would have written -- so the projection needs no pass of its own over its output.
+// the two 8-element groups a thread owns (first half / second half of a head row), from fp16 rows or from the partials
 template <bool SLAB>
-__device__ __forceinline__ half8 rope_src8(const half_t* qkv, const float* slab, int splits, size_t split_stride, size_t off) {
-    if (!SLAB) return *(const half8*)(qkv + off);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) {
-        const floatx4 a = *(const floatx4*)(slab + s * split_stride + off), b = *(const floatx4*)(slab + s * split_stride + off + 4);
+__device__ __forceinline__ void rope_src8x2(const half_t* qkv, const float* slab, int splits, size_t split_stride, size_t off1,
+                                            size_t off2, half8& x1, half8& x2) {
+    if (!SLAB) { x1 = *(const half8*)(qkv + off1); x2 = *(const half8*)(qkv + off2); return; }
+    const float* const sp[2] = {slab + off1, slab + off2};
+    floatx4 lo[2], hi[2];
+    slab_sum8<2>(sp, splits, split_stride, lo, hi);          // every partial of both groups in flight at once
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+    for (int j = 0; j < 4; ++j) {
+        x1[j] = (half_t)lo[0][j]; x1[4 + j] = (half_t)hi[0][j];
+        x2[j] = (half_t)lo[1][j]; x2[4 + j] = (half_t)hi[1][j];
     }
-    half8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
-    return o;
 }
 
 template <bool SLAB>
@@ -279,17 +279,19 @@ __global__ void rope_kv_write_kernel(const half_t* qkv, const float* slab, int s
     if (hj >= n_heads + h_kv) {                // V: plain copy into the slot
         if (slot < 0 || slot >= m) return;
         half_t* dst = v_layer + ((size_t)(hj - n_heads - h_kv) * m + slot) * d;
-        *(half8*)(dst + c * 8) = rope_src8<SLAB>(qkv, slab, splits, split_stride, src + c * 8);
-        *(half8*)(dst + half_d + c * 8) = rope_src8<SLAB>(qkv, slab, splits, split_stride, src + half_d + c * 8);
+        half8 v1, v2;
+        rope_src8x2<SLAB>(qkv, slab, splits, split_stride, src + c * 8, src + half_d + c * 8, v1, v2);
+        *(half8*)(dst + c * 8) = v1;
+        *(half8*)(dst + half_d + c * 8) = v2;
         return;
     }
     const int64_t pos = position_ids[i];
-    const half8 x1 = rope_src8<SLAB>(qkv, slab, splits, split_stride, src + c * 8);
-    const half8 x2 = rope_src8<SLAB>(qkv, slab, splits, split_stride, src + half_d + c * 8);
     const half8 c1 = *(const half8*)(cos_tab + (size_t)pos * d + c * 8);
     const half8 c2 = *(const half8*)(cos_tab + (size_t)pos * d + half_d + c * 8);
     const half8 s1 = *(const half8*)(sin_tab + (size_t)pos * d + c * 8);
     const half8 s2 = *(const half8*)(sin_tab + (size_t)pos * d + half_d + c * 8);
+    half8 x1, x2;
+    rope_src8x2<SLAB>(qkv, slab, splits, split_stride, src + c * 8, src + half_d + c * 8, x1, x2);
     half8 o1, o2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

@@ -51,17 +51,26 @@ logits_stats_kernel(const half_t* __restrict__ logits, int64_t ld, const int32_t
     const half_t* x = logits + row * ld;
     float y[PART_CH * 8];
     float lmax = -INFINITY;
+    half8 xv[PART_CH];
+#pragma unroll
+    for (int c = 0; c < PART_CH; ++c) {                     // every load of the thread in flight before the first use
+        const int e0 = part_elem(p, c, t, 0);
+        if (e0 < vocab) xv[c] = *(const half8*)(x + e0);
+    }
+    if (copy_dst) {
+#pragma unroll
+        for (int c = 0; c < PART_CH; ++c) {
+            const int e0 = part_elem(p, c, t, 0);
+            if (e0 < vocab) *(half8*)(copy_dst + (int64_t)r * ld_dst + e0) = xv[c];
+        }
+    }
 #pragma unroll
     for (int c = 0; c < PART_CH; ++c) {
-        const int e0 = part_elem(p, c, t, 0);
-        half8 v;
-        if (e0 < vocab) {
-            v = *(const half8*)(x + e0);
-            if (copy_dst) *(half8*)(copy_dst + (int64_t)r * ld_dst + e0) = v;
-        }
+        const bool in = part_elem(p, c, t, 0) < vocab;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float yy = (e0 < vocab) ? (float)(half_t)div_rn((float)v[j], temperature) : -INFINITY;
+            const float q = (float)(half_t)div_rn((float)xv[c][j], temperature);
+            const float yy = in ? q : -INFINITY;
             y[c * 8 + j] = yy;
             lmax = fmaxf(lmax, yy);
         }
@@ -185,16 +194,15 @@ sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const 
         for (int c = 0; c < PART_CH; ++c) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                // computed for every element and selected at the end (branch-free: chunks past the row end hold garbage)
                 const int e = part_elem(p, c, t, j);
-                C v = 0;
-                if (part_elem(p, c, t, 0) < vocab) {
-                    const float yy = (float)(half_t)div_rn((float)xv[c][j], temperature);
-                    const half_t q = (half_t)div_rn(exp_fast(yy - M), z);
-                    const float lu = log_fast(uv[c][j]);
-                    const float key = (q == (half_t)0.0f) ? -INFINITY : div_rn(lu, (float)q);
-                    v = ((C)f32_to_ordered(key) << (sizeof(C) * 4)) + (C)1 + (C)(0xfffffffeu - (uint32_t)e);
-                }
-                comp[c * 8 + j] = v;
+                const float yy = (float)(half_t)div_rn((float)xv[c][j], temperature);
+                const half_t q = (half_t)div_rn(exp_fast(yy - M), z);
+                const float lu = log_fast(uv[c][j]);
+                const float kq = div_rn(lu, (float)q);
+                const float key = (q == (half_t)0.0f) ? -INFINITY : kq;
+                const C v = ((C)f32_to_ordered(key) << (sizeof(C) * 4)) + (C)1 + (C)(0xfffffffeu - (uint32_t)e);
+                comp[c * 8 + j] = (part_elem(p, c, t, 0) < vocab) ? v : (C)0;
             }
         }
     } else if (WOR == 1) {
@@ -211,27 +219,34 @@ sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const 
         for (int c = 0; c < PART_CH; ++c) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                // computed for every element and selected at the end (branch-free; vocab % 8 == 0: chunks are in or out as
+                // a whole, chunks past the row end hold garbage)
                 const int e = part_elem(p, c, t, j);
-                C v = 0;
-                if (part_elem(p, c, t, 0) < vocab) {            // vocab % 8 == 0: chunks are in or out as a whole
-                    const float yy = (float)(half_t)div_rn((float)xv[c][j], temperature);
-                    const half_t q = (half_t)div_rn(exp_fast(yy - M), z);
-                    const half_t lu = (half_t)log_fast((float)uv[c][j]);
-                    // lu / 0 = -inf (lu < 0 always: u < 1); otherwise the correctly rounded quotient
-                    const half_t key = (q == (half_t)0.0f) ? (half_t)(-INFINITY) : (half_t)div_rn((float)lu, (float)q);
-                    v = Comp<C>::make(f16_to_ordered(key), e);
-                }
-                comp[c * 8 + j] = v;
+                const float yy = (float)(half_t)div_rn((float)xv[c][j], temperature);
+                const half_t q = (half_t)div_rn(exp_fast(yy - M), z);
+                const half_t lu = (half_t)log_fast((float)uv[c][j]);
+                // lu / 0 = -inf (lu < 0 always: u < 1); otherwise the correctly rounded quotient
+                const half_t kq = (half_t)div_rn((float)lu, (float)q);
+                const half_t key = (q == (half_t)0.0f) ? (half_t)(-INFINITY) : kq;
+                const C v = Comp<C>::make(f16_to_ordered(key), e);
+                comp[c * 8 + j] = (part_elem(p, c, t, 0) < vocab) ? v : (C)0;
             }
         }
     } else {
+        half8 xv[PART_CH];
+#pragma unroll
+        for (int c = 0; c < PART_CH; ++c) {                      // both loads in flight before the first use
+            const int e0 = part_elem(p, c, t, 0);
+            if (e0 < vocab) xv[c] = *(const half8*)(x + e0);
+        }
 #pragma unroll
         for (int c = 0; c < PART_CH; ++c) {
             const int e0 = part_elem(p, c, t, 0);
-            half8 v;
-            if (e0 < vocab) v = *(const half8*)(x + e0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) comp[c * 8 + j] = (e0 < vocab) ? Comp<C>::make(f16_to_ordered(v[j]), e0 + j) : (C)0;
+            for (int j = 0; j < 8; ++j) {
+                const C v = Comp<C>::make(f16_to_ordered(xv[c][j]), e0 + j);
+                comp[c * 8 + j] = (e0 < vocab) ? v : (C)0;
+            }
         }
     }
     C* dst = cand + ((size_t)r * parts + p) * k;

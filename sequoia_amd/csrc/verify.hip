@@ -97,7 +97,8 @@ __device__ __forceinline__ void row_softmax_f16(const half_t* __restrict__ x, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xv = (float)v[j];
-            const float yy = (float)(half_t)((__builtin_fabsf(xv) < INFINITY) ? div_t(xv) : xv);   // +-inf / NaN pass through (T > 0)
+            const float qv = div_t(xv);                         // evaluated unconditionally: no branch per element
+            const float yy = (float)(half_t)((__builtin_fabsf(xv) < INFINITY) ? qv : xv);   // +-inf / NaN pass through (T > 0)
             e[c * 8 + j] = yy;
             lmax = fmaxf(lmax, yy);
         }
@@ -116,7 +117,7 @@ __device__ __forceinline__ void row_softmax_f16(const half_t* __restrict__ x, in
 // cumulative mass interval, in element-index order (chunk, thread, j) and in exact integer arithmetic on the 2^-24
 // grid, contains u24 / 2^24 of the total.  Returns -1 for an all-zero distribution.  Block-uniform result.
 template <int EPT>
-__device__ __forceinline__ int block_inverse_cdf(const half2v (&p)[EPT / 2], int vocab, int t, uint32_t u24) {
+__device__ __forceinline__ int block_inverse_cdf(half2v (&p)[EPT / 2], int vocab, int t, uint32_t u24) {
     constexpr int CH = EPT / 8;
     __shared__ unsigned long long s_ct[VER_WAVES][EPT / 8];
     __shared__ unsigned long long s_scan[VER_WAVES];
@@ -134,15 +135,16 @@ __device__ __forceinline__ int block_inverse_cdf(const half2v (&p)[EPT / 2], int
         if ((t & 63) == 0) s_ct[t >> 6][c] = wsum;
     }
     __syncthreads();
-    unsigned long long ctot[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
+    // two passes over the 16 x CH wave sums in LDS (broadcast reads) instead of a register array of chunk totals: the
+    // 64-bit totals were what spilled at the 128-VGPR cap of a 1024-thread workgroup
+    auto chunk_total = [&](int c) {
         unsigned long long acc = 0ull;
 #pragma unroll
         for (int w2 = 0; w2 < VER_WAVES; ++w2) acc += s_ct[w2][c];
-        ctot[c] = acc;
-        total += acc;
-    }
+        return acc;
+    };
+#pragma unroll
+    for (int c = 0; c < CH; ++c) total += chunk_total(c);
     if (total == 0ull) { __syncthreads(); return -1; }
     const unsigned long long thr = (__umul64hi((unsigned long long)u24, total) << 40) |
                                    (((unsigned long long)u24 * total) >> 24);
@@ -151,8 +153,9 @@ __device__ __forceinline__ int block_inverse_cdf(const half2v (&p)[EPT / 2], int
     bool found = false;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        if (!found && run + ctot[c] > thr) { cstar = c; base = run; found = true; }
-        run += ctot[c];
+        const unsigned long long ct = chunk_total(c);
+        if (!found && run + ct > thr) { cstar = c; base = run; found = true; }
+        run += ct;
     }
     unsigned long long mine = 0ull;
 #pragma unroll
@@ -175,13 +178,19 @@ __device__ __forceinline__ int block_inverse_cdf(const half2v (&p)[EPT / 2], int
     if (mine > 0ull && excl <= thr && thr < excl + mine) {
         unsigned long long acc = excl;
         int pick = -1;
+        // the one thread that holds the quantile converts its chunk again: without the barrier the compiler keeps all EPT
+        // grid values of the first pass alive for this loop (32 registers -> spills at the 128-VGPR cap)
+#pragma unroll
+        for (int k2 = 0; k2 < EPT / 2; ++k2) asm volatile("" : "+v"(p[k2]));
+        int tt = t;                                              // likewise the element ids: recomputed, not kept
+        asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if (c == cstar) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     acc += (unsigned long long)(uint32_t)((float)H2(p, c * 8 + j) * 16777216.0f);
-                    if (pick < 0 && acc > thr) pick = v_elem(c, t, j);
+                    if (pick < 0 && acc > thr) pick = v_elem(c, tt, j);
                 }
             }
         }
@@ -262,38 +271,46 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
         uint32_t masked = 0u;
         const half_t* xd = draft_logits + (size_t)node * vocab;
         const RcpDiv div_t(temperature);
-        auto load_y = [&](float (&y)[EPT]) {
-            float lmax = -INFINITY;
+        half8 xrow[CH];                    // the draft row's chunks of this thread, (re)loaded by fetch_row()
+        auto fetch_row = [&]() {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int e0 = v_elem(c, t, 0);
-                half8 v = neg_inf8();
-                if (e0 < vocab) v = *(const half8*)(xd + e0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xv = (float)v[j];
-                    float yy = (float)(half_t)((__builtin_fabsf(xv) < INFINITY) ? div_t(xv) : xv);   // +-inf / NaN pass through (T > 0)
-                    yy = ((masked >> (c * 8 + j)) & 1u) ? -INFINITY : yy;
-                    y[c * 8 + j] = yy;
-                    lmax = fmaxf(lmax, yy);
-                }
+                xrow[c] = neg_inf8();
+                if (e0 < vocab) xrow[c] = *(const half8*)(xd + e0);
             }
-            return lmax;
         };
         float mx, z;
-        auto rebase = [&]() {             // e <- exp(y - max y), z <- sum e
-            float y[EPT];
-            mx = block_max_f32<VER_WAVES>(load_y(y), s_f);
+        auto rebase = [&]() {             // e <- exp(y - max y), z <- sum e; y = h(x / T) replaces x in xrow (fp16: no fp32 copy of the row)
+            float lmax = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xv = (float)xrow[c][j];
+                    const float qv = div_t(xv);
+                    half_t yy = (half_t)((__builtin_fabsf(xv) < INFINITY) ? qv : xv);   // +-inf / NaN pass through (T > 0)
+                    yy = ((masked >> (c * 8 + j)) & 1u) ? (half_t)(-INFINITY) : yy;
+                    xrow[c][j] = yy;
+                    lmax = fmaxf(lmax, (float)yy);
+                }
+            }
+            mx = block_max_f32<VER_WAVES>(lmax, s_f);
             float lsum = 0.f;
 #pragma unroll
             for (int k4 = 0; k4 < EPT / 4; ++k4) {
                 floatx4 ev;
 #pragma unroll
-                for (int h4 = 0; h4 < 4; ++h4) { ev[h4] = exp_fast(y[4 * k4 + h4] - mx); lsum += ev[h4]; }
+                for (int h4 = 0; h4 < 4; ++h4) {
+                    const int i = 4 * k4 + h4;
+                    ev[h4] = exp_fast((float)xrow[i >> 3][i & 7] - mx);
+                    lsum += ev[h4];
+                }
                 s_e4[k4 * VER_THREADS + t] = ev;
             }
             z = block_sum_f32<VER_WAVES>(lsum, s_f);
         };
+        fetch_row();
         rebase();
 
         for (int jc = 0; jc < nc; ++jc) {
@@ -310,9 +327,11 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             const RcpDiv div_sf(sf), div_z(z);
             // broadcast e[tok], p[tok] from the owning thread
             if (mine) s_tok[0] = *e_tok_ptr;
+            float p_sel = 0.f;                                   // register tok_local of the owner: a select chain, one quotient
 #pragma unroll
-            for (int i = 0; i < EPT; ++i)
-                if (mine && i == tok_local) s_tok[1] = scaled ? (float)(half_t)div_sf((float)H2(p, i)) : (float)H2(p, i);
+            for (int i = 0; i < EPT; ++i) p_sel = (i == tok_local) ? (float)H2(p, i) : p_sel;
+            const float p_div = div_sf(p_sel);
+            if (mine) s_tok[1] = scaled ? (float)(half_t)p_div : p_sel;
             __syncthreads();
             const float e_tok = s_tok[0];
             const half_t q_tok = (half_t)div_z(e_tok);
@@ -326,18 +345,30 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             }
             ok = ok && tok_ok;
             if (ok) { accepted = child; break; }
+            // the rejected token sat at the maximum (exp(0) is exactly 1): the exponentials will be rebased after this
+            // rejection.  (SQ_VERIFY_PREFETCH_ROW issues the row's re-read from L2 here, under the residual pass: the 16
+            // registers it holds across the pass push the kernel over its 128-VGPR cap -- 17 spilled -- so it is off.)
+            const bool will_rebase = !REPLACE && e_tok == 1.0f;
+#ifdef SQ_VERIFY_PREFETCH_ROW
+            if (will_rebase) fetch_row();
+#endif
             // reject: p <- relu(p - q) / sum(relu(p - q));  draft_logits[tok] <- -65504 (=> q[tok] = 0)
             uint32_t lint = 0u;
             float nsum = 0.f;
             const half2v zero2 = {(half_t)0.0f, (half_t)0.0f};
 #pragma unroll
             for (int k4 = 0; k4 < EPT / 4; ++k4) {
+                // at most two LDS columns in flight: hoisting all EPT / 4 reads costs 32 registers that the prefetched
+                // draft row needs (4 waves per SIMD hide the LDS latency)
+                if ((k4 & 1) == 0) __builtin_amdgcn_sched_barrier(0);
                 const floatx4 ev = s_e4[k4 * VER_THREADS + t];
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int k2 = 2 * k4 + h2;
                     half2v pi = p[k2];
-                    if (scaled) { pi[0] = (half_t)div_sf((float)pi[0]); pi[1] = (half_t)div_sf((float)pi[1]); }
+                    // p / sf unconditionally: before the first rejection sf = 1 and the correctly rounded quotient is p itself
+                    // (a test of `scaled` here compiled to one exec-mask branch per register pair)
+                    pi[0] = (half_t)div_sf((float)pi[0]); pi[1] = (half_t)div_sf((float)pi[1]);
                     half2v q;
                     q[0] = (half_t)div_z(ev[2 * h2]); q[1] = (half_t)div_z(ev[2 * h2 + 1]);
                     // relu_(p - q) in packed fp16 (one rounding, like the reference's fp16 tensor op); a NaN difference
@@ -361,7 +392,11 @@ verify_nodes_kernel(const half_t* __restrict__ target_logits, const half_t* __re
             if (nan_flag) break;          // every later comparison with NaN is false: all rejected
             if (REPLACE) continue;        // q is unchanged
             z = red.fsum;
-            if (e_tok == 1.0f) rebase();  // the rejected token sat at the maximum (exp(0) is exactly 1)
+#ifdef SQ_VERIFY_PREFETCH_ROW
+            if (will_rebase) rebase();
+#else
+            if (will_rebase) { fetch_row(); rebase(); }
+#endif
         }
         if (nan_flag) nrej = nc;
     }

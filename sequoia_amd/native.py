@@ -66,6 +66,7 @@ PROTOTYPES = {
     "sq_repack_rows_frag_f16": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "sq_add_rmsnorm_slabs_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sq_embed_rmsnorm_f16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "sq_embed_stage_rmsnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sq_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_add_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_silu_mul_frag_f16": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -474,6 +474,26 @@ class HipOps:
                                             float(eps), self._stream()), "sq_embed_rmsnorm_f16")
         return out
 
+    def embed_stage_rmsnorm(self, stage, embed, weight, x_out, out, eps, out_frag=False):
+        """embed_rmsnorm with the forward's inputs staged in the same launch.  stage = (dst_ids, dst_pos, dst_storage, ctx,
+        tokens, depth, n_tree, rel_slot0, rel_kv_len, step, advance): the arguments of stage_tree_inputs."""
+        dst_ids, dst_pos, dst_storage, ctx, tokens, depth, n_tree, rel_slot0, rel_kv_len, step, advance = stage
+        for t, n in ((dst_ids, "dst_ids"), (dst_pos, "dst_pos"), (dst_storage, "dst_storage"), (tokens, "tokens")):
+            _need(t, torch.int64, n)
+        _need(ctx, torch.int32, "ctx"); _need(depth, torch.int32, "depth"); _need(step, torch.int32, "step")
+        _need(embed, torch.float16, "embed"); _need(weight, torch.float16, "weight")
+        _need(x_out, torch.float16, "x_out"); _need(out, torch.float16, "out")
+        rows, hidden = x_out.shape
+        assert dst_ids.numel() == rows and dst_pos.numel() == rows and dst_storage.numel() == rows and depth.numel() >= n_tree
+        assert embed.shape[1] == hidden
+        check(self.lib.sq_embed_stage_rmsnorm_f16(dst_ids.data_ptr(), dst_pos.data_ptr(), dst_storage.data_ptr(), ctx.data_ptr(),
+                                                  tokens.data_ptr(), depth.data_ptr(), int(n_tree), int(rel_slot0),
+                                                  int(rel_kv_len), step.data_ptr(), 1 if advance else 0, embed.data_ptr(),
+                                                  embed.shape[0], weight.data_ptr(), x_out.data_ptr(), out.data_ptr(),
+                                                  1 if out_frag else 0, rows, hidden, float(eps), self._stream()),
+              "sq_embed_stage_rmsnorm_f16")
+        return out
+
     def rmsnorm_frag(self, x, weight, out_frag, eps):
         _need(x, torch.float16, "x"); _need(weight, torch.float16, "weight"); _need(out_frag, torch.float16, "out_frag")
         hidden = x.shape[-1]

@@ -31,6 +31,7 @@ def test_step_graph_equals_synchronous_steps(name):
     draft, target = build_engines(z, meta, DEV)
     tree = make_tree(z, meta, draft, target, DEV, step_graph=True)
     assert tree.state is not None and tree.state.graph is not None
+    assert tree.state.fwd_target.tree.stage is not None        # staging inside the forwards' first launch (default)
     tree.construct_grow_map()
     valid, a, _, term = tree.verify()
     assert int(a) == want[0][0] and np.array_equal(valid.cpu().numpy(), want[0][1])
@@ -101,3 +102,71 @@ def test_eos_inside_the_pipeline_keeps_the_finished_text(name):
     upto = a_end - 1 if tree._compact_when_terminal else want[-2][0]
     ka, kb = target.engine.kv_cache.k_cache[..., :upto, :], t2.engine.kv_cache.k_cache[..., :upto, :]
     assert torch.equal(ka, kb)
+
+
+@pytest.mark.parametrize("rows,hidden,frag,advance", [(34, 768, True, False), (1, 768, True, True), (128, 4096, True, False),
+                                                       (19, 1024, False, False), (129, 8192, True, False)])
+def test_embed_stage_rmsnorm_equals_stage_then_embed(rows, hidden, frag, advance):
+    """sq_embed_stage_rmsnorm_f16 (the first launch of a forward in the device-driven step) == sq_stage_tree_inputs followed by
+    sq_embed_rmsnorm_f16: the same staged ids / positions / slots / context, step block and rows, bit for bit."""
+    from sequoia_amd.native import SQ_STEP_GT, SQ_STEP_INDEX, SQ_STEP_INTS, SQ_STEP_NEXT_GT
+    from sequoia_amd.ops import HipOps
+    hip = HipOps()
+    g = torch.Generator().manual_seed(rows * 31 + hidden)
+    V, n_tree, M = 5000, 140, 600
+    embed = (torch.randn(V, hidden, generator=g) * 0.5).half().to(DEV)
+    w = (1.0 + 0.1 * torch.randn(hidden, generator=g)).half().to(DEV)
+    tokens = torch.randint(0, V, (M,), generator=g).to(DEV)
+    tokens[260] = V + 7                                              # out-of-range id: clamped like sq_embed_rmsnorm_f16
+    depth = torch.randint(0, 9, (n_tree,), generator=g, dtype=torch.int32).to(DEV)
+    rel_slot0, rel_kv = (-1, 0) if rows == 1 else (3, 3 + rows)
+    outs = []
+    for fused in (False, True):
+        step = torch.zeros(SQ_STEP_INTS, dtype=torch.int32, device=DEV)
+        step[SQ_STEP_GT], step[SQ_STEP_NEXT_GT], step[SQ_STEP_INDEX] = 250, 257, 11
+        ids = torch.full((rows,), -5, dtype=torch.long, device=DEV)
+        pos, sto = ids.clone(), ids.clone()
+        ctx = torch.zeros(3, dtype=torch.int32, device=DEV)
+        x = torch.zeros(rows, hidden, dtype=torch.float16, device=DEV)
+        h = torch.zeros(hip.frag_shape(rows, hidden) if frag else (rows, hidden), dtype=torch.float16, device=DEV)
+        stage = (ids, pos, sto, ctx, tokens, depth, n_tree, rel_slot0, rel_kv, step, advance)
+        if fused:
+            hip.embed_stage_rmsnorm(stage, embed, w, x, h, 1e-5, out_frag=frag)
+        else:
+            hip.stage_tree_inputs(*stage)
+            hip.embed_rmsnorm(ids, embed, w, x, h, 1e-5, out_frag=frag)
+        torch.cuda.synchronize()
+        outs.append([t.cpu() for t in (ids, pos, sto, ctx, step, x, h)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    gt = 257 if advance else 250
+    assert int(outs[1][4][SQ_STEP_GT]) == gt and int(outs[1][4][SQ_STEP_INDEX]) == (12 if advance else 11)
+    assert outs[1][2].tolist() == list(range(gt + rel_slot0, gt + rel_slot0 + rows))
+
+
+def test_step_graph_with_separate_staging_launches(monkeypatch):
+    """SEQUOIA_FUSE_STAGE=0: sq_stage_tree_inputs in front of every forward instead of the staging inside the forward's first
+    launch (the default, which test_step_graph_equals_synchronous_steps covers on every trace) -- same committed tokens."""
+    from sequoia_amd.Tree import step_graph
+    monkeypatch.setattr(step_graph, "FUSE_STAGE", False)
+    z, meta = load_trace("B_seq128")
+    n_steps = int(z["n_steps"])
+    want = _sync_run(z, meta, n_steps)
+    draft, target = build_engines(z, meta, DEV)
+    tree = make_tree(z, meta, draft, target, DEV, step_graph=True)
+    assert tree.state is not None and tree.state.graph is not None and tree.state.fwd_target.tree.stage is None
+    tree.construct_grow_map()
+    valid, a, _, term = tree.verify()
+    assert int(a) == want[0][0] and np.array_equal(valid.cpu().numpy(), want[0][1])
+    tree.begin_pipeline()
+    s = 1
+    while s < n_steps:
+        while (tree.can_enqueue(meta["M"]) and len(tree._pipe["inflight"]) < 2
+               and s + len(tree._pipe["inflight"]) < n_steps):
+            tree.enqueue_step()
+        a, n_acc, bonus, term = tree.collect_step()
+        assert a == want[s][0] and bonus == int(want[s][1][-1]), f"step {s}"
+        s += 1
+    tree.end_pipeline()
+    torch.cuda.synchronize()
+    assert np.array_equal(tree.tokens[:want[-1][0] + 1].cpu().numpy(), want[-1][1])
