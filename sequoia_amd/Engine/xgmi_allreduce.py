@@ -82,8 +82,11 @@ class XgmiAllReduce:
         return ar
 
     def _self_check(self) -> bool:
-        """A few reductions of rank-dependent data against dist.all_reduce (which also keeps the ranks in step); all
-        ranks must agree that all ranks passed."""
+        """A few reductions of rank-dependent data against dist.all_reduce (which also keeps the ranks in step), the
+        all-gather against dist.all_gather, the all-reduce + skip + RMSNorm kernel against the all-reduce followed by
+        sq_add_rmsnorm_f16; all ranks must agree that all ranks passed.  Every rank runs every check to the end whatever it
+        finds (the checks are collectives: a rank that left early would strand the others), the kernels' spins are
+        bounded."""
         ok = True
         gen = torch.Generator(device="cpu")
         for i, n in enumerate((8, 4096, 129 * 1024, min(self.max_elems, 129 * 8192))):
@@ -96,7 +99,6 @@ class XgmiAllReduce:
             torch.cuda.synchronize(self.device)
             if self.status() != 0 or not torch.allclose(got.float(), want, rtol=0, atol=2e-2 * self.world):
                 ok = False
-                break
             # bit-identical on every rank (each element is reduced by exactly one rank)
             same = got.clone().view(torch.int16).to(torch.int32)
             lo, hi = same.clone(), same.clone()
@@ -104,8 +106,7 @@ class XgmiAllReduce:
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
             if not torch.equal(lo, hi):
                 ok = False
-                break
-        if ok and self.max_gather_elems >= 8 * self.world:
+        if self.max_gather_elems >= 8 * self.world:
             v = max(8, (min(4000, self.max_gather_elems // (self.world * 5)) // 8) * 8)
             for rows in (1, 5):
                 gen.manual_seed(777 + rows + 10 * self.rank)
@@ -116,7 +117,24 @@ class XgmiAllReduce:
                 torch.cuda.synchronize(self.device)
                 if self.status() != 0 or not torch.equal(got, torch.cat(parts, dim=1)):
                     ok = False
-                    break
+        from ..ops import get_ops
+        ops = get_ops()
+        for rows, hidden in ((1, 256), (5, 1024), (129, 1024)):
+            if not self.fits_rows(rows, hidden) or rows * hidden > self.max_elems:
+                continue                                          # (same decision on every rank: sizes only)
+            gen.manual_seed(4242 + rows + self.rank)
+            part = torch.randn(rows, hidden, generator=gen).to(torch.float16).to(self.device)
+            gen.manual_seed(4242 + rows)                          # replicated residual stream and weight
+            x0 = torch.randn(rows, hidden, generator=gen).to(torch.float16).to(self.device)
+            g = (1.0 + 0.1 * torch.randn(hidden, generator=gen)).to(torch.float16).to(self.device)
+            red = self(part.clone().reshape(-1)).reshape(rows, hidden)
+            x_ref, o_ref = x0.clone(), torch.empty_like(x0)
+            ops.add_rmsnorm(red, x_ref, x_ref, g, o_ref, 1e-5)
+            x, out = x0.clone(), torch.empty_like(x0)
+            self.reduce_add_rmsnorm(part, x, g, out, 1e-5, False)
+            torch.cuda.synchronize(self.device)
+            if self.status() != 0 or not torch.equal(x, x_ref) or not torch.equal(out, o_ref):
+                ok = False
         verdicts = [None] * self.world
         dist.all_gather_object(verdicts, ok, group=self.group)
         if not all(verdicts):
