@@ -156,11 +156,17 @@ def kernel_rooflines(cfg, loop, device):
             def proj(name=name, tiles=tiles, splits=splits, n_out=n_out, k=k, xf=xf, out=out, silu=silu):
                 w = ts.frag(name, li[0] % L)
                 li[0] += 1
+                if silu and splits > 1:
+                    # split-K SwiGLU plan (tensor-parallel shards, Engine/ts_linear.py::forward_ts): the layer runs as a
+                    # plain [2 inter] x k projection into fp32 partials, the activation is a pass over them
+                    ops.linear_ts(xf, w, n, 2 * n_out, k, tiles=tiles, splits=splits, slab=ts._slab)
+                    ops.silu_mul_slabs(ts._slab, splits, out, n, n_out, out_frag=True)
+                    return
                 ops.linear_ts(xf, w, n, n_out, k, out=out, silu=silu, out_frag=silu, tiles=tiles, splits=splits,
                               slab=ts._slab if splits > 1 else None)
             t = timeit(proj, 128, 32)
-            out_bytes = splits * n * n_out * 4 if splits > 1 else n * n_out * 2
             w_rows = 2 * n_out if silu else n_out          # SwiGLU: gate rows + up rows
+            out_bytes = splits * n * (w_rows if silu else n_out) * 4 if splits > 1 else n * n_out * 2
             res[f"linear_ts_{name}"] = dict(seconds=t, bytes=w_rows * k * 2 + n * k * 2 + out_bytes, launches_per_step=L,
                                             flops=2 * n * w_rows * k, plan=[tiles, splits], pmc_key=f"{name}@{(n + 15) // 16}")
     return res
