@@ -16,8 +16,8 @@ import os
 import torch
 
 from ..Engine.Llama_modules import TreeContext
-from ..native import (SQ_RES_ACCEPT_LEN, SQ_RES_BONUS, SQ_RES_N_TREE, SQ_RES_TERMINAL, SQ_RESULT_INTS, SQ_RESULT_RING,
-                      SQ_STEP_ACTIVE, SQ_STEP_GT, SQ_STEP_INDEX, SQ_STEP_INTS, SQ_STEP_NEXT_GT, SQ_VERIFY_GATHER_FIRST)
+from ..native import (SQ_RES_N_TREE, SQ_RESULT_INTS, SQ_RESULT_RING, SQ_STEP_ACTIVE, SQ_STEP_GT, SQ_STEP_INTS,
+                      SQ_VERIFY_GATHER_FIRST)
 from ..ops import get_ops
 from .Tree import _content_key
 
