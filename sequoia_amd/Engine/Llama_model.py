@@ -271,11 +271,18 @@ class _LlamaForCausalLM:
                                          self.device, self.dtype)
         # tall-skinny projections for tree forwards (<= 128 rows): fragment-major weight stream, Engine/ts_linear.py
         self.ts = TsLinearSet(weights, self.dims) if TsLinearSet.supported(weights, self.dims) else None
-        if self.ts is not None and os.environ.get("SEQUOIA_TS_EXCLUSIVE", "0") == "1":
-            self.ts.make_exclusive()
+        # One copy of the layer projections (fragment-major only, prefill in 128-row chunks on the same kernel) or two (the
+        # row-major nn.Linear layout next to it for hipBLASLt prefill)?  SEQUOIA_TS_EXCLUSIVE = 1 / 0 decides; unset ("auto")
+        # the second copy is dropped when the projections exceed a quarter of the device's memory (70B on one GPU: 138 of
+        # 288 GB) -- judged on TOTAL memory, so every rank of a tensor-parallel job decides alike.
+        if self.ts is not None:
+            mode = os.environ.get("SEQUOIA_TS_EXCLUSIVE", "auto")
+            if mode == "1" or (mode == "auto" and self.ts.layer_weight_bytes()
+                               > 0.25 * torch.cuda.get_device_properties(self.device).total_memory):
+                self.ts.make_exclusive()
         self.reduce_fn = reduce_fn                  # TP all-reduce hook (None on one GPU)
-        self.reduce_slabs_fn = None
-        self.reduce_norm_fn = None       # (partial, splits, x, weight, out, eps, out_frag): all-reduce + skip + RMSNorm                 # TP: all-reduce straight from split-K partials (xGMI kernel), optional
+        self.reduce_slabs_fn = None                 # TP: all-reduce straight from split-K partials (xGMI kernel), optional
+        self.reduce_norm_fn = None                  # TP: (partial, splits, x, weight, out, eps, out_frag) all-reduce + skip + RMSNorm
         self.gather_logits_fn = gather_logits_fn    # TP vocab all-gather hook
 
     def eval(self):

@@ -143,6 +143,12 @@ class TsLinearSet:
             self._frag[key] = t
         return t
 
+    def layer_weight_bytes(self) -> int:
+        """Bytes of the layer projections (one copy): what a second, row-major copy would cost."""
+        per_layer = sum((2 if self.shapes[n][2] else 1) * self.shapes[n][0] * self.shapes[n][1] * 2
+                        for n in ("qkv", "o", "gate_up", "down"))
+        return per_layer * len(self.W.layers)
+
     def make_exclusive(self):
         """Repack every layer projection now and release the row-major copies (layer by layer: peak = one extra layer)."""
         if self.exclusive:
