@@ -460,7 +460,38 @@ def gen_rows_fullvocab(R, out_dir):
     print("rows ->", path, f"({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def main_live(specs, out_dir):
+    """`python oracle/gen_golden.py live:<mode>:<seed> ...` with SEQUOIA_GOLDEN_OUT=<dir>: fresh traces of the reference on
+    the tiny dims (weights stored in the trace) for seeds outside the committed set -- tests/test_oracle_live_reference_cpu.py
+    runs this in a subprocess (the reference's top-level `Engine` / `Tree` / `utils` modules stay out of the test process)
+    and replays the traces on the oracle."""
+    R = import_reference()
+    tiny = (128, 344, 2, 2, 2)
+    gqa_t = (256, 344, 2, 4, 1)
+    gm = lambda p: os.path.join(REF, p)
+    for spec in specs:
+        _, mode, seed = spec.split(":")
+        seed = int(seed)
+        if mode == "stochastic":
+            run_case(R, f"live_stochastic_{seed}", gm("demo_tree.pt"), tiny, gqa_t, 1024, 96, 0.6, "stochastic", 12, 6, seed,
+                     out_dir=out_dir)
+        elif mode == "sequoia128":
+            run_case(R, f"live_sequoia128_{seed}", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), tiny, tiny,
+                     1024, 256, 0.6, "stochastic", 24, 2, seed, logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
+        elif mode == "greedy":
+            run_case(R, f"live_greedy_{seed}", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "greedy", 20, 4, seed,
+                     logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
+        else:
+            raise SystemExit(f"unknown live mode {mode}")
+
+
 def main():
+    live = [a for a in sys.argv[1:] if a.startswith("live:")]
+    if live:
+        out = os.environ.get("SEQUOIA_GOLDEN_OUT")
+        if not out:
+            raise SystemExit("live traces need SEQUOIA_GOLDEN_OUT=<directory> (they never go into tests/golden)")
+        return main_live(live, out)
     R = import_reference()
     out_dir = os.path.join(REPO, "tests", "golden")
     only = set(sys.argv[1:])                       # e.g. `python oracle/gen_golden.py D_160m13b V32k_seq128`

@@ -123,10 +123,11 @@ def make_tree(z, meta, draft, target, device, cls=None, step_graph=None):
     return tree
 
 
-def replay_trace(name, device, max_steps=None):
+def replay_trace(name, device, max_steps=None, trace=None):
     """Run the native loop on a trace's weights / prompt / noise.  Returns per-step records
-    (valid tokens, accept length) next to the reference's."""
-    z, meta = load_trace(name)
+    (valid tokens, accept length) next to the reference's.  trace = (z, meta): an already loaded trace (the live
+    traces of test_oracle_live_reference_cpu.py) instead of the committed fixture `name`."""
+    z, meta = trace if trace is not None else load_trace(name)
     draft, target = build_engines(z, meta, device)
     tree = make_tree(z, meta, draft, target, device)
     n_steps = int(z["n_steps"]) if max_steps is None else min(max_steps, int(z["n_steps"]))

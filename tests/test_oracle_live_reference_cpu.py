@@ -114,3 +114,95 @@ def test_tree_search_against_the_live_script(seed):
     tab = ts.search_tables(np.asarray(p, dtype=np.float32)[:-1], cfg["max_budget"], cfg["max_depth"])
     want = np.array([[-np.inf if x is None else x for x in row] for row in exp["results"]], dtype=np.float32)
     assert np.array_equal(tab.best, want)
+
+
+# ---- fresh traces of the reference's SpecTree / GreedyTree (seeds outside the committed fixtures) ---------------------------
+LIVE_SPECS = ["live:stochastic:301", "live:stochastic:302", "live:sequoia128:303", "live:greedy:304"]
+
+
+@pytest.fixture(scope="module")
+def live_traces(tmp_path_factory):
+    """oracle/gen_golden.py run in a SUBPROCESS (the reference's top-level Engine / Tree / utils modules never enter this
+    process) for a few seeds the committed fixtures do not contain: tiny dims, weights stored in the trace."""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path_factory.mktemp("live_traces")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SEQUOIA_GOLDEN_OUT=str(out))
+    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py")] + LIVE_SPECS, env=env, cwd=repo,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    traces = {}
+    for spec in LIVE_SPECS:
+        _, mode, seed = spec.split(":")
+        z = np.load(os.path.join(str(out), f"trace_live_{mode}_{seed}.npz"))
+        traces[spec] = (z, json.loads(bytes(z["meta_json"]).decode()))
+    return traces
+
+
+@pytest.mark.parametrize("spec", LIVE_SPECS)
+def test_live_trace_sampler_and_verifier_on_the_oracle(live_traces, spec):
+    """Every sampler call and every verification of a fresh reference run, op by op on the oracle (the checks of
+    tests/test_oracle_golden.py::test_sampler_matches_reference / test_verify_*_matches_reference)."""
+    z, meta = live_traces[spec]
+    succ, T = meta["successors"], meta["T"]
+    rejections = 0
+    for s in range(int(z["n_steps"])):
+        lvl = 0
+        while f"step{s}/samp{lvl}/logits" in z:
+            logits, want = z[f"step{s}/samp{lvl}/logits"], z[f"step{s}/samp{lvl}/out"]
+            k = want.shape[0] // logits.shape[0]
+            if meta["mode"] == "stochastic":
+                rnd = z[f"step{s}/samp{lvl}/rand"]
+                got, keys = O.sample_wor(logits, rnd, k, T), O.sample_keys(logits, rnd, T)
+            else:
+                got, keys = O.topk_ids(logits, k), logits
+            want = want.reshape(got.shape)
+            bad = got != want
+            assert (keys[np.nonzero(bad)[0], got[bad]] == keys[np.nonzero(bad)[0], want[bad]]).all(), (spec, s, lvl)
+            lvl += 1
+        assert lvl > 0
+        gt = int(z[f"step{s}/gt"])
+        tokens = z[f"step{s}/tokens_pre"].copy()
+        if meta["mode"] == "stochastic":
+            draft = z[f"step{s}/draft_logits_pre"].copy()
+            res = O.verify_stochastic(z[f"step{s}/target_logits"], draft, tokens, z["r"], succ, gt, T, int(z["bonus_u24"][s]))
+            assert res["terminal"] == int(z[f"step{s}/terminal"])
+            post = z[f"step{s}/draft_logits_post"]
+            for t in [sl - (gt - 1) for sl in res["slots"]]:
+                if len(succ[t]):
+                    assert np.array_equal(draft[t], post[t]), (spec, s, t)        # the -65504 writes (Tree/SpecTree.py:156)
+            rejections += int((draft != z[f"step{s}/draft_logits_pre"]).sum())     # rejected children: masked draft logits
+            if f"step{s}/residual" in z:
+                a16 = res["final_p"].view(np.int16).astype(np.int32)
+                b16 = z[f"step{s}/residual"].view(np.int16).astype(np.int32)
+                assert np.abs(a16 - b16).max() <= 2
+        else:
+            res = O.verify_greedy(z[f"step{s}/target_logits"], tokens, succ, gt)
+        assert res["accept_len"] == int(z[f"step{s}/accept_len"]), (spec, s)
+        valid = z[f"step{s}/valid_tokens"]
+        assert np.array_equal(tokens[:valid.shape[0]], valid), (spec, s)
+    if meta["mode"] == "stochastic":
+        assert rejections > 0                                                     # residual updates did occur
+
+
+@pytest.mark.parametrize("spec", LIVE_SPECS)
+def test_live_trace_host_loop_replay(live_traces, spec):
+    """The package's engines + trees on CPU with the oracle's ops reproduce the fresh reference run step by step (the
+    check of tests/test_host_logic_cpu.py on the committed traces)."""
+    from helpers import check_replay, replay_trace
+    from oracle.ops_adapter import OracleOps
+    from sequoia_amd import ops
+    z, meta = live_traces[spec]
+    ops.set_ops_for_testing(OracleOps())
+    try:
+        steps, tree, draft, target, z, meta = replay_trace(None, "cpu", trace=(z, meta))
+    finally:
+        ops.set_ops_for_testing(None)
+    assert len(steps) == int(z["n_steps"])
+    matched, diverged = check_replay(steps, z, meta)
+    assert diverged is None and matched == len(steps), f"{spec}: diverged at step {diverged}"
+    last = len(steps) - 1
+    assert draft.engine.kv_cache.kv_offset == int(z[f"step{last}/kv_draft"][2])
+    assert target.engine.kv_cache.kv_offset == int(z[f"step{last}/kv_target"][2])
