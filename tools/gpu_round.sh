@@ -1,0 +1,57 @@
+# One measurement pass of a round on the GPU box (run through gpurun; about 7 GPU-minutes):
+#   bash tools/gpu_round.sh r04 [tests] [pmc] [bench] [loop] [tp2]      (no stage names = all of them, in this order)
+#   tests  python -m pytest tests -m gpu -x -q + __graft_entry__.smoke()
+#   pmc    tools/pmc_r03.sh: FETCH_SIZE / WRITE_SIZE / MFMA passes of the 128-row projection plans and tree attention
+#          (separate rocprofv3 --pmc runs), summarised into profiles/<tag>_pmc.json stamped with the kernel-source sha --
+#          bench.py refuses a record measured on other sources, so this comes BEFORE the bench stage
+#   bench  the default line, the driver's command, configs C / D, rocprofv3 --kernel-trace --stats of the default command
+#   loop   rocprofv3 --kernel-trace --stats of the loop alone (--no-kernel-rooflines)
+#   tp2    configuration E tensor-parallel with two ranks on the ONE GPU (xGMI kernels over hipIpc-mapped buffers)
+# Everything is written under gpurun_out/<tag>/ (created first: a redirect into a missing directory silently skips a stage)
+# and the records the judge reads are copied to profiles/<tag>_*.
+TAG=${1:-r04}; shift
+STAGES="$*"; [ -z "$STAGES" ] && STAGES="tests pmc bench loop tp2"
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $O profiles
+has() { case " $STAGES " in *" $1 "*) return 0;; *) return 1;; esac; }
+line() { python - "$1" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d.get("roofline") or {}
+    print(sys.argv[1].split("/")[-1], round(d["value"], 1), d["unit"], round(d["ms_per_step"], 3), "ms/step", d.get("mean_accepted_len"),
+          "roof", r.get("kernel"), r.get("frac") and round(r["frac"], 3), "traffic", r.get("traffic"))
+except Exception as e:
+    print(sys.argv[1], "failed:", e)
+PY
+}
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -x -q > $O/tests_gpu.log 2>&1; grep -n "passed\|failed\|error" $O/tests_gpu.log | tail -2
+  python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+fi
+if has pmc; then
+  bash tools/pmc_r03.sh > $O/pmc_run.log 2>&1; tail -3 $O/pmc_run.log
+  [ -f gpurun_out/r3/pmc/r03_pmc.json ] && cp gpurun_out/r3/pmc/r03_pmc.json profiles/${TAG}_pmc.json
+fi
+if has bench; then
+  timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; line $O/bench_default.json
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; line $O/bench_driver_cmd.json
+  for c in C D; do
+    timeout 600 python bench.py --config $c --steps 60 --warmup 5 --no-cpu-baseline --no-autoregressive > $O/bench_config$c.json 2> $O/bench_config$c.err; line $O/bench_config$c.json
+  done
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-tuned-growmap --no-autoregressive > $O/prof.log 2>&1)
+  python tools/rocprof_summary.py $(find $O/prof -name "*results.db" | head -1) 45 > $O/kernel_stats.md; find $O/prof -name "*.db" -delete
+  cp $O/bench_default.json profiles/${TAG}_bench_default.json; cp $O/bench_driver_cmd.json profiles/${TAG}_bench_driver_cmd.json
+  cp $O/bench_configC.json profiles/${TAG}_bench_configC.json; cp $O/bench_configD.json profiles/${TAG}_bench_configD.json
+  cp $O/kernel_stats.md profiles/${TAG}_bench_kernel_stats.md
+fi
+if has loop; then
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_loop -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 120 --warmup 8 --no-kernel-rooflines --no-cpu-baseline --no-tuned-growmap --no-autoregressive > $O/prof_loop.log 2>&1)
+  python tools/rocprof_summary.py $(find $O/prof_loop -name "*results.db" | head -1) 40 > $O/kernel_stats_loop_only.md; find $O/prof_loop -name "*.db" -delete
+  cp $O/kernel_stats_loop_only.md profiles/${TAG}_bench_kernel_stats_loop_only.md; head -16 $O/kernel_stats_loop_only.md
+fi
+if has tp2; then
+  SEQUOIA_TS_EXCLUSIVE=1 SEQUOIA_BENCH_ONE_DEVICE=1 timeout 700 python bench.py --gpus 2 --config E --backend gloo --steps 8 --warmup 2 --no-cpu-baseline --no-autoregressive > $O/benchE_tp2.json 2> $O/benchE_tp2.err; line $O/benchE_tp2.json
+  cp $O/benchE_tp2.json profiles/${TAG}_bench_configE_tp2_one_gpu.json
+fi
