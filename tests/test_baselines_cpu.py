@@ -20,7 +20,11 @@ def oracle_ops():
 
 
 def test_specinfer_draws_and_verification_match_reference():
-    z, meta = load_trace("F_specinfer")
+    check_specinfer_trace(*load_trace("F_specinfer"))
+
+
+def check_specinfer_trace(z, meta):
+    """(also applied to fresh traces of the live reference: tests/test_oracle_live_reference_cpu.py)"""
     succ = meta["successors"]
     g = GrowMap.from_successors(succ)
     for s in range(int(z["n_steps"])):
@@ -43,7 +47,10 @@ def test_specinfer_draws_and_verification_match_reference():
 
 
 def test_greedys_target_draw_and_walk_match_reference():
-    z, meta = load_trace("G_greedys")
+    check_greedys_trace(*load_trace("G_greedys"))
+
+
+def check_greedys_trace(z, meta):
     succ = meta["successors"]
     n = len(succ)
     for s in range(int(z["n_steps"])):

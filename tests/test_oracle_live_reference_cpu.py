@@ -118,6 +118,7 @@ def test_tree_search_against_the_live_script(seed):
 
 # ---- fresh traces of the reference's SpecTree / GreedyTree (seeds outside the committed fixtures) ---------------------------
 LIVE_SPECS = ["live:stochastic:301", "live:stochastic:302", "live:sequoia128:303", "live:greedy:304"]
+BASELINE_SPECS = ["live:specinfer:305", "live:greedys:306"]          # the paper's comparison baselines
 
 
 @pytest.fixture(scope="module")
@@ -130,11 +131,11 @@ def live_traces(tmp_path_factory):
     out = tmp_path_factory.mktemp("live_traces")
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SEQUOIA_GOLDEN_OUT=str(out))
-    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py")] + LIVE_SPECS, env=env, cwd=repo,
+    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py")] + LIVE_SPECS + BASELINE_SPECS, env=env, cwd=repo,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     traces = {}
-    for spec in LIVE_SPECS:
+    for spec in LIVE_SPECS + BASELINE_SPECS:
         _, mode, seed = spec.split(":")
         z = np.load(os.path.join(str(out), f"trace_live_{mode}_{seed}.npz"))
         traces[spec] = (z, json.loads(bytes(z["meta_json"]).decode()))
@@ -206,3 +207,12 @@ def test_live_trace_host_loop_replay(live_traces, spec):
     last = len(steps) - 1
     assert draft.engine.kv_cache.kv_offset == int(z[f"step{last}/kv_draft"][2])
     assert target.engine.kv_cache.kv_offset == int(z[f"step{last}/kv_target"][2])
+
+
+@pytest.mark.parametrize("spec", BASELINE_SPECS)
+def test_live_trace_comparison_baselines(live_traces, spec):
+    """Fresh runs of the reference's SpecInferTree / GreedySTree: the draws with replacement, the `p >= r q` walk, the sampled
+    target tokens and the token-equality walk on the oracle (the checks of tests/test_baselines_cpu.py)."""
+    from test_baselines_cpu import check_greedys_trace, check_specinfer_trace
+    z, meta = live_traces[spec]
+    (check_specinfer_trace if meta["mode"] == "specinfer" else check_greedys_trace)(z, meta)
