@@ -484,6 +484,8 @@ def main_live(specs, out_dir):
         elif mode in ("specinfer", "greedys"):
             run_case(R, f"live_{mode}_{seed}", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, mode, 20, 4, seed,
                      logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
+        elif mode in ("spectest", "greedytest"):
+            run_probe_case(R, f"live_{mode}_{seed}", mode, tiny, 1024, 128, 0.6, 8, 16, 10, seed, noise=0.6, out_dir=out_dir)
         else:
             raise SystemExit(f"unknown live mode {mode}")
 

@@ -119,6 +119,7 @@ def test_tree_search_against_the_live_script(seed):
 # ---- fresh traces of the reference's SpecTree / GreedyTree (seeds outside the committed fixtures) ---------------------------
 LIVE_SPECS = ["live:stochastic:301", "live:stochastic:302", "live:sequoia128:303", "live:greedy:304"]
 BASELINE_SPECS = ["live:specinfer:305", "live:greedys:306"]          # the paper's comparison baselines
+PROBE_SPECS = ["live:spectest:307", "live:greedytest:308"]           # the acceptance-rate probes
 
 
 @pytest.fixture(scope="module")
@@ -131,11 +132,11 @@ def live_traces(tmp_path_factory):
     out = tmp_path_factory.mktemp("live_traces")
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SEQUOIA_GOLDEN_OUT=str(out))
-    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py")] + LIVE_SPECS + BASELINE_SPECS, env=env, cwd=repo,
+    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py")] + LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS, env=env, cwd=repo,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     traces = {}
-    for spec in LIVE_SPECS + BASELINE_SPECS:
+    for spec in LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS:
         _, mode, seed = spec.split(":")
         z = np.load(os.path.join(str(out), f"trace_live_{mode}_{seed}.npz"))
         traces[spec] = (z, json.loads(bytes(z["meta_json"]).decode()))
@@ -216,3 +217,15 @@ def test_live_trace_comparison_baselines(live_traces, spec):
     from test_baselines_cpu import check_greedys_trace, check_specinfer_trace
     z, meta = live_traces[spec]
     (check_specinfer_trace if meta["mode"] == "specinfer" else check_greedys_trace)(z, meta)
+
+
+@pytest.mark.parametrize("spec", PROBE_SPECS)
+def test_live_trace_acceptance_probes(live_traces, spec):
+    """Fresh runs of the reference's SpecTreeTest / GreedyTreeTest (fp32 noise, p >= r q in fp32, the 5-tuple) on the oracle."""
+    from test_probe_cpu import check_greedytest_trace, check_spectest_trace
+    z, meta = live_traces[spec]
+    if meta["mode"] == "spectest":
+        accepted, rejected_all = check_spectest_trace(z, meta)
+        assert accepted + rejected_all == int(z["n_steps"])
+    else:
+        check_greedytest_trace(z, meta)

@@ -23,7 +23,12 @@ def _star(w):
 
 
 def test_oracle_probe_sampler_and_verifier_match_reference():
-    z, meta = load_trace("P_spectest")
+    accepted, rejected_all = check_spectest_trace(*load_trace("P_spectest"))
+    assert accepted >= 2 and rejected_all >= 2
+
+
+def check_spectest_trace(z, meta):
+    """(also applied to fresh traces of the live reference: tests/test_oracle_live_reference_cpu.py)"""
     w, T = meta["width"], meta["T"]
     accepted = rejected_all = 0
     for s in range(int(z["n_steps"])):
@@ -42,11 +47,14 @@ def test_oracle_probe_sampler_and_verifier_match_reference():
         assert np.array_equal(tokens[:len(valid)], valid), s
         accepted += b >= 0
         rejected_all += b < 0
-    assert accepted >= 2 and rejected_all >= 2
+    return accepted, rejected_all
 
 
 def test_oracle_greedy_probe_matches_reference():
-    z, meta = load_trace("Q_greedytest")
+    check_greedytest_trace(*load_trace("Q_greedytest"))
+
+
+def check_greedytest_trace(z, meta):
     w = meta["width"]
     for s in range(int(z["n_steps"])):
         gt = len(z[f"step{s}/prefix"])
