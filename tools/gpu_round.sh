@@ -7,10 +7,20 @@
 #   bench  the default line, the driver's command, configs C / D, rocprofv3 --kernel-trace --stats of the default command
 #   loop   rocprofv3 --kernel-trace --stats of the loop alone (--no-kernel-rooflines)
 #   tp2    configuration E tensor-parallel with two ranks on the ONE GPU (xGMI kernels over hipIpc-mapped buffers)
-# Everything is written under gpurun_out/<tag>/ (created first: a redirect into a missing directory silently skips a stage)
-# and the records the judge reads are copied to profiles/<tag>_*.
+# Everything is written under gpurun_out/<tag>/ (created first: a redirect into a missing directory silently skips a stage);
+# gpurun merges that directory back.  Afterwards, LOCALLY:   bash tools/gpu_round.sh r04 collect
+# copies the records the judge reads into profiles/<tag>_* (profiles/ written on the GPU box does not come back).
 TAG=${1:-r04}; shift
 STAGES="$*"; [ -z "$STAGES" ] && STAGES="tests pmc bench loop tp2"
+if [ "$STAGES" = "collect" ]; then          # local: gpurun_out/<tag>/ -> profiles/<tag>_*
+  cd "$(dirname "$0")/.." && O=gpurun_out/$TAG
+  for pair in pmc.json:pmc.json bench_default.json:bench_default.json bench_driver_cmd.json:bench_driver_cmd.json \
+              bench_configC.json:bench_configC.json bench_configD.json:bench_configD.json kernel_stats.md:bench_kernel_stats.md \
+              kernel_stats_loop_only.md:bench_kernel_stats_loop_only.md benchE_tp2.json:bench_configE_tp2_one_gpu.json; do
+    src=$O/${pair%%:*}; [ -s $src ] && cp $src profiles/${TAG}_${pair##*:} && echo "profiles/${TAG}_${pair##*:}"
+  done
+  exit 0
+fi
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O profiles
@@ -32,7 +42,7 @@ if has tests; then
 fi
 if has pmc; then
   bash tools/pmc_r03.sh > $O/pmc_run.log 2>&1; tail -3 $O/pmc_run.log
-  [ -f gpurun_out/r3/pmc/r03_pmc.json ] && cp gpurun_out/r3/pmc/r03_pmc.json profiles/${TAG}_pmc.json
+  [ -f gpurun_out/r3/pmc/r03_pmc.json ] && cp gpurun_out/r3/pmc/r03_pmc.json $O/pmc.json && cp $O/pmc.json profiles/${TAG}_pmc.json   # (on the box: for the bench stage)
 fi
 if has bench; then
   timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; line $O/bench_default.json
@@ -42,16 +52,12 @@ if has bench; then
   done
   (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-tuned-growmap --no-autoregressive > $O/prof.log 2>&1)
   python tools/rocprof_summary.py $(find $O/prof -name "*results.db" | head -1) 45 > $O/kernel_stats.md; find $O/prof -name "*.db" -delete
-  cp $O/bench_default.json profiles/${TAG}_bench_default.json; cp $O/bench_driver_cmd.json profiles/${TAG}_bench_driver_cmd.json
-  cp $O/bench_configC.json profiles/${TAG}_bench_configC.json; cp $O/bench_configD.json profiles/${TAG}_bench_configD.json
-  cp $O/kernel_stats.md profiles/${TAG}_bench_kernel_stats.md
 fi
 if has loop; then
   (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_loop -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 120 --warmup 8 --no-kernel-rooflines --no-cpu-baseline --no-tuned-growmap --no-autoregressive > $O/prof_loop.log 2>&1)
   python tools/rocprof_summary.py $(find $O/prof_loop -name "*results.db" | head -1) 40 > $O/kernel_stats_loop_only.md; find $O/prof_loop -name "*.db" -delete
-  cp $O/kernel_stats_loop_only.md profiles/${TAG}_bench_kernel_stats_loop_only.md; head -16 $O/kernel_stats_loop_only.md
+  head -16 $O/kernel_stats_loop_only.md
 fi
 if has tp2; then
   SEQUOIA_TS_EXCLUSIVE=1 SEQUOIA_BENCH_ONE_DEVICE=1 timeout 700 python bench.py --gpus 2 --config E --backend gloo --steps 8 --warmup 2 --no-cpu-baseline --no-autoregressive > $O/benchE_tp2.json 2> $O/benchE_tp2.err; line $O/benchE_tp2.json
-  cp $O/benchE_tp2.json profiles/${TAG}_bench_configE_tp2_one_gpu.json
 fi
