@@ -7,7 +7,10 @@ that is shipped or measured.  Only tests/, __graft_entry__.smoke() and bench.py'
 
 Pinning: the reference ships no golden vectors, so the oracle is pinned
 against traces produced by running the *reference itself* in the build container
-(oracle/gen_golden.py -> tests/golden/*.npz; checked by tests/test_oracle_golden.py).
+(oracle/gen_golden.py -> tests/golden/*.npz; checked by tests/test_oracle_golden.py), and, wherever the
+reference checkout is present, against the live reference: its utils.py functions and tree_search.py on seeded
+random inputs and fresh traces of its tree classes for seeds outside the committed set
+(tests/test_oracle_live_reference_cpu.py).
 
 Arithmetic contract (what "the reference computes" means here).  The reference is fp16 torch
 code; every torch op on an fp16 tensor computes in fp32 and rounds the result to fp16 once
