@@ -484,6 +484,11 @@ def main_live(specs, out_dir):
         elif mode in ("specinfer", "greedys"):
             run_case(R, f"live_{mode}_{seed}", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, mode, 20, 4, seed,
                      logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
+        elif mode == "v32k":
+            # the real vocabulary: 68m-dims draft -> 160m-dims target on config B's growmap, seeded weights, compact logits
+            run_case(R, f"live_v32k_{seed}", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), (768, 3072, 2, 12, 12),
+                     (768, 3072, 12, 12, 12), 32000, 384, 0.6, "stochastic", 32, 3, seed, logit_gain=10.0, seeded=True,
+                     share_vocab=0.05, compact=16, branch_scale=0.005, out_dir=out_dir)
         elif mode in ("spectest", "greedytest"):
             run_probe_case(R, f"live_{mode}_{seed}", mode, tiny, 1024, 128, 0.6, 8, 16, 10, seed, noise=0.6, out_dir=out_dir)
         else:

@@ -127,7 +127,12 @@ def test_verify_stochastic_matches_reference_full_vocab(name):
     """V = 32000: the oracle's verifier on the reference's own logits.  The trace keeps the full target / draft rows
     of the nodes the reference walked (the verifier touches no other row) and every step must reproduce the
     reference's accept length, committed tokens and bonus token; rejections (residual updates) must occur."""
-    z, meta = load_trace(name)
+    margins = check_compact_verify(*load_trace(name), name)
+    assert sum(m <= 0 for m in margins) >= 3 and sum(m > 0 for m in margins) >= 3
+
+
+def check_compact_verify(z, meta, name):
+    """(also applied to fresh V = 32000 traces of the live reference: tests/test_oracle_live_reference_cpu.py)"""
     succ = meta["successors"]
     n, V = len(succ), meta["vocab"]
     margins = []
@@ -148,7 +153,7 @@ def test_verify_stochastic_matches_reference_full_vocab(name):
             a16 = res["final_p"].view(np.int16).astype(np.int32)
             b16 = z[f"step{s}/residual"].view(np.int16).astype(np.int32)
             assert np.abs(a16 - b16).max() <= 2
-    assert sum(m <= 0 for m in margins) >= 3 and sum(m > 0 for m in margins) >= 3
+    return margins
 
 
 @pytest.mark.parametrize("name", COMPACT_STOCHASTIC)
@@ -156,8 +161,11 @@ def test_sampler_matches_reference_full_vocab(name):
     """V = 32000: sampling without replacement of every tree level of step 0 against the reference's outputs.  The
     level's input rows are the trace's draft rows where they were kept (root row); the noise is regenerated from the
     recorded seed (same CPU-generator draws as Tree/SpecTree.py:60,84) and checked on the recorded probe columns."""
+    assert check_compact_sampler(*load_trace(name), name) >= 3
+
+
+def check_compact_sampler(z, meta, name):
     import torch
-    z, meta = load_trace(name)
     n, V, M = len(meta["successors"]), meta["vocab"], meta["M"]
     torch.manual_seed(meta["seed"] + 7)
     r = torch.rand(M, dtype=torch.float16).numpy()
@@ -176,7 +184,7 @@ def test_sampler_matches_reference_full_vocab(name):
             if got[c] != want[c]:
                 assert keys[got[c]] == keys[want[c]], f"{name} step {s} rank {c}"
         checked += 1
-    assert checked >= 3
+    return checked
 
 
 def test_verify_greedy_matches_reference_headline_dims():

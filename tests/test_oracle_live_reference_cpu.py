@@ -120,6 +120,7 @@ def test_tree_search_against_the_live_script(seed):
 LIVE_SPECS = ["live:stochastic:301", "live:stochastic:302", "live:sequoia128:303", "live:greedy:304"]
 BASELINE_SPECS = ["live:specinfer:305", "live:greedys:306"]          # the paper's comparison baselines
 PROBE_SPECS = ["live:spectest:307", "live:greedytest:308"]           # the acceptance-rate probes
+VOCAB_SPECS = ["live:v32k:309"]            # the real vocabulary: 68m-dims -> 160m-dims, config B's growmap, seeded weights, compact logits
 
 
 @pytest.fixture(scope="module")
@@ -132,11 +133,11 @@ def live_traces(tmp_path_factory):
     out = tmp_path_factory.mktemp("live_traces")
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SEQUOIA_GOLDEN_OUT=str(out))
-    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py")] + LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS, env=env, cwd=repo,
+    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py")] + LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS + VOCAB_SPECS, env=env, cwd=repo,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     traces = {}
-    for spec in LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS:
+    for spec in LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS + VOCAB_SPECS:
         _, mode, seed = spec.split(":")
         z = np.load(os.path.join(str(out), f"trace_live_{mode}_{seed}.npz"))
         traces[spec] = (z, json.loads(bytes(z["meta_json"]).decode()))
@@ -229,3 +230,15 @@ def test_live_trace_acceptance_probes(live_traces, spec):
         assert accepted + rejected_all == int(z["n_steps"])
     else:
         check_greedytest_trace(z, meta)
+
+
+@pytest.mark.parametrize("spec", VOCAB_SPECS)
+def test_live_trace_real_vocabulary(live_traces, spec):
+    """A fresh SpecTree run at V = 32000 (68m-dims draft -> 160m-dims target on the A100-CNN-68m-7b growmap): the oracle's
+    sampler on the root rows and its verifier on the rows of the walked path (the checks of the committed V32k_seq128 /
+    B_7b traces, tests/test_oracle_golden.py)."""
+    from test_oracle_golden import check_compact_sampler, check_compact_verify
+    z, meta = live_traces[spec]
+    assert check_compact_sampler(z, meta, spec) == int(z["n_steps"])
+    margins = check_compact_verify(z, meta, spec)
+    assert len(margins) > 0
