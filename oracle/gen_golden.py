@@ -85,8 +85,19 @@ def _skip_param_init():
     """Construct a model without running its random initialisers (seeded cases overwrite every parameter through
     load_state_dict; a 7B-dims model would spend minutes drawing numbers that are thrown away)."""
     saved = (torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters)
+    saved_init = (torch.nn.Linear.__init__, torch.nn.Embedding.__init__)
     torch.nn.Linear.reset_parameters = lambda self: None
     torch.nn.Embedding.reset_parameters = lambda self: None
+
+    def _half(init):
+        # the matrices are allocated in fp16 from the start (a 13B-dims model in fp32 would not fit this container); only
+        # Linear / Embedding: rotary tables and norms keep the reference's construction dtype
+        def run(self, *a, **k):
+            k.setdefault("dtype", torch.float16)
+            return init(self, *a, **k)
+        return run
+    torch.nn.Linear.__init__ = _half(saved_init[0])
+    torch.nn.Embedding.__init__ = _half(saved_init[1])
     try:
         from transformers.modeling_utils import no_init_weights
         cm = no_init_weights()
@@ -97,6 +108,7 @@ def _skip_param_init():
             yield
     finally:
         torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters = saved
+        torch.nn.Linear.__init__, torch.nn.Embedding.__init__ = saved_init
 
 
 def make_engine(R, outer, inner, model_cls, cfg, M, seed, logit_gain, dt=torch.float16, skip_init=False):
@@ -130,9 +142,13 @@ def kv_checksum(engine):
 
 def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, prompt_len, max_steps, seed,
              logit_gain=24.0, share_weights=0.0, out_dir=None, seeded=False, share_vocab=0.0, compact=0,
-             branch_scale=1.0, lead=None):
+             branch_scale=1.0, lead=None, top_p=1.0, draft_lm_scale=1.0):
     """mode: 'stochastic' (SpecTree), 'greedy' (GreedyTree), 'specinfer' (SpecInferTree: draws with replacement)
-    or 'greedys' (GreedySTree: greedy draft tree, target token sampled per node)."""
+    or 'greedys' (GreedySTree: greedy draft tree, target token sampled per node).
+    top_p < 1: the nucleus filter of utils.py:65-77 on the target logits (tests/testbed.py:28 defaults to --P 0.9).
+    draft_lm_scale (seeded pairs): the correlated draft's lm_head is multiplied by it after `correlate` -- a narrower draft
+    normalises its residual stream over fewer dimensions than the target, so its logits come out flatter by a constant
+    factor; the scale puts the two distributions at the same temperature (deeper accepted paths)."""
     RU = R["RU"]
     g = torch.load(growmap_path, weights_only=False)
     n = g["size"]
@@ -159,11 +175,13 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
         sd_d = SW.seeded_state_dict(draft_dims, vocab, 2000 + seed, logit_gain, branch_scale=branch_scale)
         if share_vocab > 0.0:
             SW.correlate(sd_d, sd_t, share_vocab, 3000 + seed)
+        SW.scale_lm_head(sd_d, draft_lm_scale)
         for eng, sd in ((draft, sd_d), (target, sd_t)):
-            missing, unexpected = eng.engine.model.load_state_dict(sd, strict=False)
+            missing, unexpected = eng.engine.model.load_state_dict(sd, strict=False, assign=big)
             assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing), (missing, unexpected)
         seeded_meta = dict(draft_seed=2000 + seed, target_seed=1000 + seed, share_vocab=share_vocab,
                            share_seed=3000 + seed, branch_scale=branch_scale, lead=list(lead) if lead else None,
+                           **({"draft_lm_scale": float(draft_lm_scale)} if draft_lm_scale != 1.0 else {}),
                            draft_checksum=str(SW.checksum(sd_d)),
                            target_checksum=str(SW.checksum(sd_t)))
     else:
@@ -233,7 +251,7 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
         cls = {"stochastic": R["SpecTree"], "greedy": R["GreedyTree"], "specinfer": R["SpecInferTree"],
                "greedys": R["GreedySTree"]}[mode]
         torch.manual_seed(seed + 7)  # noise seed: r then rand are drawn inside the ctor
-        tree = cls(prefix=prefix, device="cpu", temperature=T, top_p=1.0, draft_kv_len=0, target_kv_len=0,
+        tree = cls(prefix=prefix, device="cpu", temperature=T, top_p=top_p, draft_kv_len=0, target_kv_len=0,
                    draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
                    grow_map=g, attn_mask=torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16),
                    sequence=None, new_tokens_buffer=None, parents_buffer=None,
@@ -348,6 +366,7 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
     meta = dict(name=name, growmap=os.path.relpath(growmap_path, REF), draft_dims=list(draft_dims),
                 target_dims=list(target_dims), vocab=vocab, M=M, T=T, mode=mode, prompt_len=prompt_len,
                 seed=seed, logit_gain=logit_gain, share_weights=share_weights, n_tree=int(n),
+                **({"top_p": float(top_p)} if top_p != 1.0 else {}),
                 successors=g["Successors"], torch=torch.__version__, seeded=seeded_meta, compact=int(compact))
     arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     out_dir = out_dir or os.path.join(REPO, "tests", "golden")

@@ -361,26 +361,47 @@ def verify_stochastic(target_logits16, draft_logits16, tokens, r16, successors, 
 def top_p_filter(logits16, top_p, temperature):
     """Rows [n, V] fp16 -> copy with the removed tokens set to -inf.
 
-    Reference: sort descending, cumulative_probs = cumsum(softmax(sorted/T)) (fp16), token at
-    sorted rank k is removed iff cumulative_probs[k-1] > top_p (the comparison runs in fp16: the
-    python scalar is cast to the tensor dtype).  Restated with the cumulative mass summed exactly on
-    the 2^-24 grid and then rounded to fp16 (torch accumulates in fp32 and rounds: identical except
-    on rounding boundaries), ties between equal logits ordered by token id (torch.sort leaves the
-    order of equal keys unspecified)."""
+    Reference (utils.py:65-77): sort descending; cumulative_probs = cumsum(softmax(sorted / T)); the token at sorted
+    rank k is removed iff cumulative_probs[k-1] > top_p.  Restated with torch's CPU arithmetic for fp16 tensors:
+      * the softmax runs over the SORTED row (same values, fp32 sum in that order) and is rounded to fp16;
+      * torch.cumsum on a CPU fp16 tensor accumulates SEQUENTIALLY in fp32 (at::acc_type<Half, false> = float,
+        aten/src/ATen/native/cpu/ReduceOpsKernel.cpp cumsum_cpu_kernel) and rounds every prefix to fp16.  Every fp16
+        value is a multiple of 2^-24, so every prefix below 1 is exactly representable in fp32: the sequential fp32
+        cumsum IS the exact sum up to the cut (and beyond 1 every comparison is true whatever the rounding).  The
+        "exact mass" rule of the native kernel (sq_top_p_filter_f16) is therefore the reference's rule, not an
+        approximation of it;
+      * `cumulative_probs > top_p` compares in fp16 (the python scalar is cast to the tensor dtype);
+      * torch.sort: equal logits are ordered by ascending token id here.  torch's CPU sort of fp16 is NOT stable
+        (x86-simd-sort on AVX-512 FP16 hosts; `stable=False` is the default), so which of several exactly equal logits
+        sit before the cut is implementation-defined in the reference.  Equal logits carry equal probability: the
+        filtered distribution is the same up to relabelling those tokens.
+    Against the reference itself (tests/test_oracle_golden.py, tests/test_oracle_live_reference_cpu.py): identical on every
+    row except for the identity of equal-logit tokens at the cut.  A probability whose exp() differs from torch's in the
+    last fp32 ulp could additionally move the cut by that element's fp16 ulp of mass; not observed on the test rows."""
     out = logits16.copy()
     th16 = np.float16(top_p)
+    V = logits16.shape[1]
     for r in range(logits16.shape[0]):
-        p16 = scaled_softmax_f16(logits16[r], temperature)
         xf = f(logits16[r]).copy()
         xf[np.isnan(xf)] = np.inf
-        order = np.lexsort((np.arange(xf.shape[0]), -xf))
-        w = _grid_int(np.where(np.isnan(p16), np.float16(0), p16))[order]
-        before = np.concatenate([[0], np.cumsum(w)[:-1]])                 # mass ranked strictly before
-        c16 = (before.astype(np.float64) / _TWO24).astype(np.float16)
-        remove = c16 > th16
-        remove[0] = False
+        order = np.lexsort((np.arange(V), -xf))                       # stable descending sort
+        p16 = scaled_softmax_f16(logits16[r][order], temperature)      # softmax of the sorted row
+        p32 = np.where(np.isnan(p16), np.float16(0), p16).astype(np.float32)
+        c16 = np.cumsum(p32, dtype=np.float32).astype(np.float16)      # sequential fp32 accumulation, fp16 prefixes
+        filt = c16 > th16
+        remove = np.zeros(V, dtype=bool)
+        remove[1:] = filt[:-1]
         out[r, order[remove]] = np.float16(-np.inf)
     return out
+
+
+def top_p_mass_difference(logits16, a16, b16, temperature):
+    """Per row: the probability mass (under softmax(logits / T)) of the tokens that exactly one of the two filtered
+    copies a16 / b16 removed -- the measure in which two nucleus filters are compared (a token count says nothing: the
+    cut sits in a tail of ~1e-5-mass tokens)."""
+    p = scaled_softmax_f16(logits16, temperature).astype(np.float64)
+    diff = np.isinf(f(a16)) != np.isinf(f(b16))
+    return np.where(diff, p, 0.0).sum(axis=1), diff.sum(axis=1)
 
 
 # --------------------------------------------------------------------------------------------

@@ -94,6 +94,14 @@ def correlate(draft_sd: dict, target_sd: dict, noise: float, seed: int):
     return draft_sd
 
 
+def scale_lm_head(draft_sd: dict, scale: float):
+    """lm_head *= scale (after `correlate`): a draft narrower than its target normalises the residual stream over fewer
+    dimensions, so the shared lm_head slice yields logits that are flatter by a constant factor; see gen_golden.run_case."""
+    if scale != 1.0:
+        draft_sd["lm_head.weight"] = (draft_sd["lm_head.weight"].float() * float(scale)).half()
+    return draft_sd
+
+
 def checksum(sd: dict) -> int:
     """Order-dependent 64-bit checksum of the fp16 bit patterns (wrap-around uint64 arithmetic)."""
     acc = np.uint64(1469598103934665603)

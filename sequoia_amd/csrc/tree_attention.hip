@@ -44,7 +44,20 @@ struct AttnParams {
     const uint64_t* bitmask;
     int words;
     const int32_t* ctx;     // optional device override of {q_slot0, gt, kv_len} (hipGraph replays)
+    int xcd_span;           // h_kv < 8: XCDs one KV head's workgroups are dealt over (host: att_xcd_span)
 };
+
+// Fewer than 8 KV heads (a tensor-parallel shard of a GQA model: 8 query heads on ONE KV head at TP = 8; tiny test
+// models): every XCD that runs a workgroup of a KV head pulls that head's K/V into its own L2, so the head's
+// (query head, query tile) items stay on as few XCDs as give every item a compute unit of its own (32 per XCD, one
+// 512-thread workgroup each) -- never more than the head's share 8 / h_kv of the chip.  70B shard, 8:1, 129 rows:
+// 72 items -> 3 XCDs instead of 8 (PMC HBM traffic of that launch was 2.74x algorithmic with the heads dealt round-robin).
+static inline int att_xcd_span(int n_heads, int h_kv, int n_tiles) {
+    const int budget = 8 / h_kv;                                   // >= 1 for h_kv < 8
+    const int items = (n_heads / h_kv) * n_tiles;
+    const int want = (items + 31) / 32;
+    return want < 1 ? 1 : (want > budget ? budget : want);
+}
 
 // max / sum over the four 16-lane groups holding the same query (lanes l, l^16, l^32, l^48) with the
 // gfx950 VALU lane swaps (v_permlane16_swap / v_permlane32_swap) instead of LDS-routed ds_bpermute
@@ -117,9 +130,13 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
         head = kvh_x * grp + within / n_tiles;
         q0 = (within % n_tiles) * ATT_BM;
     } else {
-        head = xcd + 8 * (jj / n_tiles);
-        if (head >= P.n_heads) return;       // uniform per block
-        q0 = (jj % n_tiles) * ATT_BM;
+        // KV head kvh owns XCDs [kvh * budget, kvh * budget + span); its items (query head, tile) are dealt over them
+        const int budget = 8 / P.h_kv;
+        const int kvh_x = xcd / budget, j = xcd - kvh_x * budget;
+        const int item = jj * P.xcd_span + j;
+        if (kvh_x >= P.h_kv || j >= P.xcd_span || item >= grp * n_tiles) return;       // uniform per block
+        head = kvh_x * grp + item / n_tiles;
+        q0 = (item % n_tiles) * ATT_BM;
     }
     const int kvh = head / grp;
     const half_t* kbase = P.k + (size_t)kvh * P.m * D;
@@ -383,8 +400,10 @@ extern "C" int sq_tree_attention_f16(const void* q, const void* k_layer, const v
     }
     if (q_len == 0) return SQ_OK;
     const int n_tiles = (q_len + ATT_BM - 1) / ATT_BM;
-    const int slots = h_kv >= 8 ? 8 * ((h_kv + 7) / 8) * (n_heads / h_kv) : 8 * ((n_heads + 7) / 8);
-    dim3 grid(slots * n_tiles), block(ATT_THREADS);
+    P.xcd_span = h_kv < 8 ? att_xcd_span(n_heads, h_kv, n_tiles) : 0;
+    const int blocks = h_kv >= 8 ? 8 * ((h_kv + 7) / 8) * (n_heads / h_kv) * n_tiles
+                                 : 8 * (((n_heads / h_kv) * n_tiles + P.xcd_span - 1) / P.xcd_span);
+    dim3 grid(blocks), block(ATT_THREADS);
     hipStream_t st = (hipStream_t)stream;
     const int mk = mask_mode == 0 ? 0 : (P.words <= 2 ? 1 : 2);
 #define SQ_ATT(DD, MM) hipLaunchKernelGGL((tree_attention_kernel<DD, MM>), grid, block, 0, st, P)

@@ -258,7 +258,10 @@ static int ts_dispatch(const TsParams& P, int silu, int nt, hipStream_t st) {
         if (nt <= 2) ts_go<MT, 2, true>(P, st);
         else if (nt <= 4) ts_go<MT, 4, true>(P, st);
         else if (nt <= 6) ts_go<MT, 6, true>(P, st);
-        else return SQ_EUNSUPPORTED;
+        else if constexpr (MT <= 8) {                   // 4 gate+up units per workgroup (13B gate_up: 864 units -> 216 workgroups,
+            if (nt <= 8) ts_go<MT, 8, true>(P, st);     // one resident wave of them instead of 288 = 256 + 32)
+            else return SQ_EUNSUPPORTED;
+        } else return SQ_EUNSUPPORTED;
         return SQ_OK;
     }
     if (nt <= 2) ts_go<MT, 2, false>(P, st);

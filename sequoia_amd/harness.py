@@ -124,6 +124,8 @@ class Loop:
         self.tree = None
         self.cur_len = 0
         self.prefill_steps = 0       # steps that carried a prompt's target prefill (the first verify of every prompt)
+        self.prefill_seconds = 0.0   # wall time of those steps (construct_grow_map + verify; verify ends on a result read)
+        self.prompts_done = 0        # prompts generated to the end (max_new tokens, EOS, or a terminal step)
         # device-driven steps under tensor parallelism too: the step block, the result ring and the decisions are per
         # rank and identical on every rank (replicated draft / sampler / verifier, same noise), so every rank replays
         # the same whole-step graph -- collectives included -- without any broadcast
@@ -143,13 +145,25 @@ class Loop:
                              **(dict(step_graph=True) if self.pipelined else {}))
         self.cur_len = len(p)
 
-    def run_steps(self, k_steps, on_step=None, on_accept=None):
+    def run_prompts(self, n_prompts, max_steps=100000):
+        """Run until n_prompts more prompts are complete (each from its prefill-bearing first step to max_new tokens / EOS):
+        the reference's metric as tests/testbed.py:78-95 computes it -- total_time / tokens over WHOLE prompts, the
+        target prefill inside the first verify included.  Returns (seconds, new_tokens, steps)."""
+        if self.tree is not None:          # a prompt left half-way by run_steps(): start from a fresh one
+            if self.pipelined and getattr(self.tree, "_pipe", None) is not None:
+                self.tree.end_pipeline()
+            self.tree = None
+        return self.run_steps(max_steps, stop_after_prompts=self.prompts_done + n_prompts)
+
+    def run_steps(self, k_steps, on_step=None, on_accept=None, stop_after_prompts=None):
         """Run exactly k_steps speculation steps; per-prompt setup (tree constructor + draft
         prefill) is outside the timed brackets like the reference (tests/testbed.py:67-79).
         `on_step(tree, terminate)` is called after every verify() (synchronous mode), `on_accept(accept_length)` after
-        every step in both modes.  Returns (seconds, new_tokens, steps)."""
+        every step in both modes.  stop_after_prompts: also stop once self.prompts_done reaches it (run_prompts).
+        Returns (seconds, new_tokens, steps)."""
         total_t, new_tok, done = 0.0, 0, 0
-        while done < k_steps:
+        more = (lambda: True) if stop_after_prompts is None else (lambda: self.prompts_done < stop_after_prompts)
+        while done < k_steps and more():
             if self.tree is None:
                 self._new_prompt()
             _sync(self.device)
@@ -169,10 +183,13 @@ class Loop:
                     length = a if terminate else a + 1
                     last = bonus
                 else:
-                    if tree.target_kv_len == 0:
-                        self.prefill_steps += 1
+                    is_prefill = tree.target_kv_len == 0
+                    t_p = time.perf_counter()
                     tree.construct_grow_map()
                     valid, a, _, terminate = tree.verify()
+                    if is_prefill:
+                        self.prefill_steps += 1
+                        self.prefill_seconds += time.perf_counter() - t_p
                     length = valid.shape[0]
                     last = int(valid[-1])              # the reference's EOS test reads the last token (tests/testbed.py:80)
                     if on_step is not None:
@@ -188,6 +205,7 @@ class Loop:
                     if piped:
                         tree.end_pipeline()
                     self.tree = None
+                    self.prompts_done += 1
             if piped and self.tree is not None:
                 tree.end_pipeline()                    # k_steps reached mid-prompt: back to host-side state
             _sync(self.device)

@@ -28,6 +28,20 @@ def pytest_sessionstart(session):
     build(force=False, verbose=False)
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How many margin-limited decisions the session ACCEPTED (tests/helpers.py::ESCAPES).  Committed fixtures are
+    fail-closed, so every entry comes from fresh random inputs or live traces; the expected count on a green run of the
+    committed suite is 0."""
+    try:
+        import helpers
+    except Exception:
+        return
+    esc = helpers.ESCAPES
+    terminalreporter.write_line(f"margin-limited decisions accepted: {len(esc)} (committed fixtures: 0 by construction)")
+    for label, m in esc:
+        terminalreporter.write_line(f"  {label}: margin {m:.3e}")
+
+
 def load_trace(name):
     z = np.load(os.path.join(GOLDEN, f"trace_{name}.npz"))
     meta = json.loads(bytes(z["meta_json"]).decode())

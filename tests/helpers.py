@@ -8,6 +8,64 @@ import numpy as np
 import torch
 
 from conftest import load_trace
+from sequoia_amd.native import SQ_RES_N_TREE, SQ_RESULT_INTS
+
+
+# Every margin-limited decision a test ACCEPTED (label, margin): printed in the session summary (conftest.py).  Replays of
+# the committed fixtures never add to it -- they are fail-closed (assert_replay_complete(committed=True)); only fresh
+# inputs (random trees, live traces of the reference) may leave the oracle, and only at the ONE decision where the two
+# accepted paths part, with that decision's own margin below 1e-3 (split_margin).
+ESCAPES: list = []
+
+
+def note_escape(label, margin):
+    ESCAPES.append((str(label), float(margin)))
+    print(f"margin-limited decision accepted: {label} (margin {float(margin):.3e})")
+
+
+def split_margin(succ, gt, want_slots, got_slots, margins):
+    """The oracle's margin p - r q at the decision where the path `got_slots` leaves the oracle's `want_slots`.
+    `margins` = the oracle's margins in walk order (one per child it tried).  None when the paths do not part at a
+    decision of this tree (then nothing excuses the difference)."""
+    node, base = 0, 0
+    for i in range(max(len(want_slots), len(got_slots)) + 1):
+        w = want_slots[i] - (gt - 1) if i < len(want_slots) else None
+        g = got_slots[i] - (gt - 1) if i < len(got_slots) else None
+        ch = succ[node]
+        if (w is not None and w not in ch) or (g is not None and g not in ch):
+            return None                               # not a path of this tree
+        jw = ch.index(w) if w is not None else len(ch)
+        jg = ch.index(g) if g is not None else len(ch)
+        if w != g:
+            k = base + min(jw, jg)
+            return margins[k] if k < len(margins) else None
+        if w is None:
+            return None
+        base += jw + 1
+        node = w
+    return None
+
+
+def assert_top_p_equal_up_to_ties(logits16, got16, want16, label=""):
+    """Two nucleus-filtered copies of the same fp16 rows must be IDENTICAL except for the identity of tokens inside ONE
+    class of exactly equal logits -- the class the cut falls into: torch.sort on the CPU is not stable for fp16
+    (x86-simd-sort), so which of several equal-logit tokens sit before the cut is implementation-defined there; equal
+    logits carry equal probability, so the filtered distributions agree up to relabelling those tokens.  Asserted per row:
+    the same NUMBER of tokens removed, and every token the two copies disagree on carries the same logit value."""
+    import numpy as np
+    ga, wa = np.isinf(got16) & (got16 < 0), np.isinf(want16) & (want16 < 0)
+    keep_same = ~ga & ~wa
+    assert np.array_equal(got16[keep_same], want16[keep_same]), f"{label}: a kept logit changed value"
+    ties = 0
+    for r in range(logits16.shape[0]):
+        d = np.where(ga[r] != wa[r])[0]
+        if d.size == 0:
+            continue
+        assert ga[r].sum() == wa[r].sum(), f"{label} row {r}: {ga[r].sum()} vs {wa[r].sum()} tokens removed"
+        vals = np.unique(logits16[r][d])
+        assert vals.size == 1, f"{label} row {r}: the copies differ on tokens with different logits {vals}"
+        ties += d.size
+    return ties
 
 
 def state_dict_of(z, prefix):
@@ -56,6 +114,7 @@ def trace_state_dicts(z, meta):
                                   branch_scale=sm.get("branch_scale", 1.0))
     if sm["share_vocab"] > 0.0:
         SW.correlate(sd_d, sd_t, sm["share_vocab"], sm["share_seed"])
+    SW.scale_lm_head(sd_d, sm.get("draft_lm_scale", 1.0))
     assert str(SW.checksum(sd_d)) == sm["draft_checksum"] and str(SW.checksum(sd_t)) == sm["target_checksum"], \
         "seeded weights differ from the ones the reference trace was generated with (torch CPU generator drift)"
     if cache is not None and n_params < (3 << 30):         # (the 7B-dims pair is shared in-process instead: 27 GB on disk)
@@ -108,7 +167,7 @@ def make_tree(z, meta, draft, target, device, cls=None, step_graph=None):
         from sequoia_amd.Tree.SpecInferTree import SpecInferTree
         cls = {"stochastic": SpecTree, "greedy": GreedyTree, "specinfer": SpecInferTree, "greedys": GreedySTree}[meta["mode"]]
     torch.manual_seed(meta["seed"] + 7)          # same noise seed as oracle/gen_golden.py
-    tree = cls(prefix=torch.from_numpy(z["prompt"]), device=device, temperature=meta["T"], top_p=1.0, draft_kv_len=0,
+    tree = cls(prefix=torch.from_numpy(z["prompt"]), device=device, temperature=meta["T"], top_p=meta.get("top_p", 1.0), draft_kv_len=0,
                target_kv_len=0, draft_model_engine=draft, target_model_engine=target, max_length=M, max_target_seq=M,
                grow_map=g, attn_mask=torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16, device=device),
                sequence=None, new_tokens_buffer=None, parents_buffer=None,
@@ -137,7 +196,9 @@ def replay_trace(name, device, max_steps=None, trace=None):
         tokens_pre = tree.tokens.cpu().numpy().copy()
         draft_logits = tree.draft_logits.float().cpu().numpy().copy()
         valid, a, _, terminal = tree.verify()
-        out.append(dict(valid=valid.cpu().numpy().copy(), accept_len=int(a), terminal=bool(terminal),
+        lr = getattr(tree, "last_result", None)
+        slots = [int(x) for x in lr[SQ_RESULT_INTS:SQ_RESULT_INTS + int(lr[SQ_RES_N_TREE])]] if lr is not None else None
+        out.append(dict(valid=valid.cpu().numpy().copy(), accept_len=int(a), terminal=bool(terminal), slots=slots,
                         tokens_pre=tokens_pre, draft_logits=draft_logits,
                         target_logits=tree.target_logits.float().cpu().numpy().copy(),
                         ref_valid=z[f"step{s}/valid_tokens"],
@@ -245,17 +306,35 @@ def _ancestors(c, parent):
     return out
 
 
-def assert_replay_complete(name, steps, tree, z, meta, matched, diverged, commit_order="reference"):
-    """Every step of a trace must reproduce the reference's committed tokens.  A run with sampled decisions may leave
-    the reference only where that is attributable to the (asserted) logit tolerance: at the first differing step the
+# Committed traces whose GPU replay is KNOWN to leave the reference at a step for a reason the test then proves:
+# F_specinfer draws 64 tokens per step by exact inverse CDF at recorded 24-bit uniforms; the GPU's draft logits differ from
+# the reference's CPU logits within the asserted tolerance, which moves every CDF boundary by ~1e-4 of mass, and one of the
+# trace's 256 uniforms falls inside such a sliver -- the native run draws the neighbouring token there.  The kernels are
+# exact on their own inputs (asserted: the oracle, fed the native logits, reproduces the native step token for token).
+KNOWN_INPUT_LIMITED = {"F_specinfer": "one iid draw lands within the logit tolerance of a CDF boundary"}
+
+
+def assert_replay_complete(name, steps, tree, z, meta, matched, diverged, commit_order="reference", committed=True):
+    """Every step of a trace must reproduce the reference's committed tokens.
+
+    committed = True (the fixtures under tests/golden): FAIL-CLOSED -- every step of every committed trace is known to
+    reproduce on the MI355X, so any divergence is a regression, whatever the margins of the step look like.
+
+    committed = False (fresh traces: live runs of the reference on new seeds): a run with sampled decisions may leave the
+    reference only where that is attributable to the (asserted) logit tolerance: at the first differing step the
     oracle, fed the NATIVE run's own logits / tokens / noise, must reproduce the native run's decisions -- i.e. the
-    kernels are exact on their inputs and only the inputs differ within tolerance -- or a decision margin
-    |p[tok] - r q[tok]| is below 1e-3 (one fp16 ulp of p).  Greedy traces must match in every step."""
+    kernels are exact on their inputs and only the inputs differ within tolerance -- or the paths part at ONE decision
+    whose own margin |p[tok] - r q[tok]| is below 1e-3 (one fp16 ulp of p).  Greedy: check_replay has
+    asserted the recorded margin of the first differing decision."""
     from oracle import ops_np as O
     n_steps = int(z["n_steps"])
     if diverged is None:
         assert matched == n_steps, f"{name}: replay stopped after {matched} of {n_steps} steps"
         return
+    known = KNOWN_INPUT_LIMITED.get(name) if committed else None
+    assert not committed or known is not None, (
+        f"{name}: the replay leaves the committed reference trace at step {diverged} (accept length "
+        f"{steps[diverged]['accept_len']} vs {steps[diverged]['ref_accept_len']}); committed fixtures must reproduce in every step")
     mode = meta["mode"]
     if mode == "greedy":
         # check_replay has asserted a recorded decision margin below the logit tolerance at this step
@@ -292,9 +371,23 @@ def assert_replay_complete(name, steps, tree, z, meta, matched, diverged, commit
         res = O.verify_stochastic(tl, dl, tokens, z["r"], succ, gt, T, int(z["bonus_u24"][diverged]), margins=margins,
                                   replace=(mode == "specinfer"), gather_first=(commit_order == "lossless"))
     same = res["accept_len"] == rec["accept_len"] and np.array_equal(tokens[:len(rec["valid"])], rec["valid"])
-    tight = bool(margins) and min(abs(m) for m in margins) < 1e-3
-    assert same or tight, (f"{name} step {diverged}: native decisions differ from the oracle on the native run's own "
-                           f"inputs and no decision margin is below 1e-3 ({margins})")
+    if known is not None:
+        # a committed trace with a documented input-limited step: the kernels must be EXACT on the native run's own inputs
+        # (the oracle reproduces the native step), and the native tree may differ from the reference's in ONE draw only
+        ref_t = rec["ref_tokens_pre"][gt - 1:gt + n - 1]
+        parent = {c: p for p, ch in enumerate(succ) for c in ch}
+        first_diff = [c for c in range(1, n) if got_t[c] != ref_t[c] and all(got_t[a] == ref_t[a] for a in _ancestors(c, parent))]
+        assert same and len(first_diff) <= 1, (f"{name} step {diverged}: documented as '{known}', but the native step differs "
+                                               f"from the oracle on its own inputs or in {len(first_diff)} independent draws")
+        note_escape(f"{name} step {diverged}: {known}", 0.0)
+        return
+    if same:
+        note_escape(f"{name} step {diverged}: inputs differ within the logit tolerance, kernels exact on their own inputs", 0.0)
+        return
+    m = split_margin(succ, gt, res["slots"], rec["slots"], margins) if rec.get("slots") is not None and mode != "greedys" else None
+    assert m is not None and abs(m) < 1e-3, (f"{name} step {diverged}: native decisions differ from the oracle on the native "
+                                             f"run's own inputs and the decision where the paths part has margin {m}")
+    note_escape(f"{name} step {diverged}", m)
 
 
 # ---- a prompt that ends on EOS in the middle of the device-driven loop ------------------------------------------------

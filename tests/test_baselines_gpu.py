@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_trace
-from helpers import assert_replay_complete, check_replay, replay_trace
+from helpers import assert_replay_complete, check_replay, note_escape, replay_trace, split_margin
 from oracle import ops_np as O
 from test_hip_kernels import csr, dev, random_tree
 
@@ -70,9 +70,7 @@ def test_verify_specinfer_on_reference_trace(ops):
         o_tokens = tokens.copy()
         want = O.verify_specinfer(target, draft.copy(), o_tokens, z["r"], succ, gt, meta["T"], u24, margins=margins)
         assert np.array_equal(draft_after, draft)                    # the draft logits are never modified
-        if res[0] != want["accept_len"]:
-            assert min(abs(m) for m in margins) < 1e-3
-            continue
+        assert res[0] == want["accept_len"], (s, res[:8], want["accept_len"])      # committed fixture: fail-closed
         a = want["accept_len"]
         assert list(res[8:8 + res[1]]) == want["slots"] and res[3] == want["terminal"]
         assert np.array_equal(tok_after[:a + 1], o_tokens[:a + 1])
@@ -105,8 +103,10 @@ def test_verify_specinfer_random(ops, V, n, seed):
             agree += 1
             a = want["accept_len"]
             assert np.array_equal(tok_after[:a], o_tokens[:a])
-        else:
-            assert min(abs(m) for m in margins) < 1e-3
+        else:       # fresh random inputs: the paths may part at ONE decision whose own margin is inside one fp16 ulp of p
+            m = split_margin(succ, gt, want["slots"], [int(x) for x in res[8:8 + res[1]]], margins)
+            assert m is not None and abs(m) < 1e-3, f"trial {trial}: paths split at a decision with margin {m}"
+            note_escape(f"test_verify_specinfer_random V={V} n={n} seed={seed} trial {trial}", m)
     assert agree >= total - 1
 
 

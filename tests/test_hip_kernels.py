@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, STOCHASTIC_TRACES, load_trace
+from helpers import assert_top_p_equal_up_to_ties, note_escape, split_margin
 from oracle import ops_np as O
 
 pytestmark = pytest.mark.gpu
@@ -253,8 +254,8 @@ def _run_verify_stochastic(ops, target, draft, tokens, r16, succ, gt, T, u24):
 @pytest.mark.parametrize("name", STOCHASTIC_TRACES)
 def test_verify_stochastic_on_reference_traces(ops, name):
     """Inputs recorded from the reference run; the kernel must reproduce the reference's accepted
-    tokens, bonus and -65504 writes.  A decision is allowed to differ only when the oracle's
-    accept margin |p[tok] - r*q[tok]| is below 1 fp16 ulp of p (exp() last-ulp effects)."""
+    tokens, bonus and -65504 writes in EVERY step (committed fixtures are fail-closed: margin excuses exist only for
+    fresh random inputs, test_verify_stochastic_random)."""
     z, meta = load_trace(name)
     succ = meta["successors"]
     n = len(succ)
@@ -268,9 +269,8 @@ def test_verify_stochastic_on_reference_traces(ops, name):
         margins = []
         o_tokens, o_draft = tokens.copy(), draft.copy()
         want = O.verify_stochastic(target, o_draft, o_tokens, z["r"], succ, gt, meta["T"], u24, margins=margins)
-        if res[0] != want["accept_len"]:
-            assert min(abs(m) for m in margins) < 1e-3, (name, s, res[:8], want)
-            continue
+        # committed fixture: fail-closed (every step of every committed trace reproduces; no margin excuse)
+        assert res[0] == want["accept_len"], (name, s, res[:8], want["accept_len"], want["slots"])
         assert res[1] == want["n_tree"] and res[3] == want["terminal"] and res[4] == want["reason"]
         assert list(res[8:8 + res[1]]) == want["slots"]
         a = want["accept_len"]
@@ -325,30 +325,10 @@ def test_verify_stochastic_random(ops, V, n, seed):
             assert np.array_equal(tok_after[:a], o_tokens[:a])
         else:
             # the paths split at ONE decision, and that decision's margin p - r q (oracle values) is inside one fp16 ulp
-            m = _split_margin(succ, gt, want["slots"], [int(x) for x in res[8:8 + res[1]]], margins)
+            m = split_margin(succ, gt, want["slots"], [int(x) for x in res[8:8 + res[1]]], margins)
             assert m is not None and abs(m) < 1e-3, f"trial {trial}: paths split at a decision with margin {m}"
+            note_escape(f"test_verify_stochastic_random V={V} n={n} seed={seed} trial {trial}", m)
     assert agree >= total - 1
-
-
-def _split_margin(succ, gt, want_slots, got_slots, margins):
-    """The oracle's margin p - r q at the decision where the kernel's accepted path leaves the oracle's."""
-    node, base = 0, 0
-    for i in range(max(len(want_slots), len(got_slots)) + 1):
-        w = want_slots[i] - (gt - 1) if i < len(want_slots) else None
-        g = got_slots[i] - (gt - 1) if i < len(got_slots) else None
-        ch = succ[node]
-        if (w is not None and w not in ch) or (g is not None and g not in ch):
-            return None                               # not a path of this tree
-        jw = ch.index(w) if w is not None else len(ch)
-        jg = ch.index(g) if g is not None else len(ch)
-        if w != g:
-            k = base + min(jw, jg)
-            return margins[k] if k < len(margins) else None
-        if w is None:
-            return None
-        base += jw + 1
-        node = w
-    return None
 
 
 def _cdf_interval_distance(p16, token, u24):
@@ -470,18 +450,30 @@ def test_top_p_filter(ops, V, gain, top_p):
     d = dev(logits)
     ops.top_p_filter(d, top_p, 0.6)
     got = d.cpu().numpy()
-    # exp() last-ulp differences can move the cut by a token; otherwise bit-identical
-    diff = (np.isinf(got) != np.isinf(want)).sum(axis=1)
-    assert diff.max() <= 2, diff
+    # The kernel's exact-mass cut IS the reference's rule (fp16 probabilities are multiples of 2^-24: torch's sequential fp32
+    # cumsum is exact below 1), ties ordered by token id like the oracle.  What can differ is a probability whose exp()
+    # lands on the other side of an fp16 rounding boundary (last fp32 ulp): the prefix sums then shift by that element's
+    # fp16 ulp and the cut moves over the tokens inside that shift.  Allowance, as probability MASS: one fp16 ulp of the
+    # cumulative sum at the cut (2^-11 below 1).
+    mass, count = O.top_p_mass_difference(logits, got, want, 0.6)
+    assert mass.max() <= 2.0 ** -11, (mass, count)
     same = np.isinf(got) == np.isinf(want)
     assert np.array_equal(got[same], want[same])
-    # reference outputs on the golden rows
-    if V == 32000 and top_p == 0.9:
+    print(f"top_p V={V} P={top_p}: kernel vs oracle differing tokens per row {count.tolist()}, mass {mass.max():.2e}")
+    # the reference's own outputs on the golden rows: identical up to the identity of equal-logit tokens at the cut
+    if V == 32000:
         z = np.load(f"{GOLDEN}/rows_v32000.npz")
+        key = {0.9: "topp09", 0.5: "topp05"}[top_p]
         for i in range(4):
             d = dev(z[f"wor{i}/logits"])
-            ops.top_p_filter(d, 0.9, 0.6)
-            assert (np.isinf(d.cpu().numpy()) != np.isinf(z[f"wor{i}/topp09"])).sum(axis=1).max() <= 6
+            ops.top_p_filter(d, top_p, 0.6)
+            g = d.cpu().numpy()
+            m, c = O.top_p_mass_difference(z[f"wor{i}/logits"], g, z[f"wor{i}/{key}"], 0.6)
+            if m.max() > 0:      # only inside a tie class (same count removed, one logit value), or within the mass allowance
+                try:
+                    assert_top_p_equal_up_to_ties(z[f"wor{i}/logits"], g, z[f"wor{i}/{key}"], f"wor{i} P={top_p}")
+                except AssertionError:
+                    assert m.max() <= 2.0 ** -11, (i, m, c)
 
 
 @pytest.mark.parametrize("H,Hkv,D,q,splits", [(4, 4, 64, 7, 2), (32, 32, 128, 128, 2), (8, 1, 128, 129, 3)])

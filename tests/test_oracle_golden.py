@@ -252,17 +252,19 @@ def test_inverse_cdf_is_exact_and_distribution_correct():
 
 
 def test_top_p_filter_matches_reference():
-    """utils.get_sampling_logits (utils.py:65-77) on V = 32000 rows: the set of removed tokens equals
-    the reference's except inside exact ties at the cut (torch.sort's tie order) / fp32-vs-exact
-    accumulation on a rounding boundary: at most a handful of tokens out of 32000."""
+    """utils.get_sampling_logits (utils.py:65-77) on V = 32000 rows: the oracle removes exactly the reference's tokens,
+    except for WHICH of several exactly-equal logits sit before the cut (torch's CPU sort of fp16 is not stable).  The
+    cumulative sums themselves are reproduced exactly: fp16 probabilities are multiples of 2^-24, so torch's sequential
+    fp32 cumsum is exact below 1 and equals the integer-grid sum."""
+    from helpers import assert_top_p_equal_up_to_ties
     z = np.load(f"{GOLDEN}/rows_v32000.npz")
+    exact = 0
     for i in range(4):
         for tp, key in ((0.9, "topp09"), (0.5, "topp05")):
             got = O.top_p_filter(z[f"wor{i}/logits"], tp, 0.6)
             want = z[f"wor{i}/{key}"]
-            kept_equal = np.isinf(got) == np.isinf(want)
-            assert (~kept_equal).sum(axis=1).max() <= 6, (i, tp)
-            assert np.array_equal(got[kept_equal & ~np.isinf(got)], want[kept_equal & ~np.isinf(want)])
+            exact += assert_top_p_equal_up_to_ties(z[f"wor{i}/logits"], got, want, f"wor{i} P={tp}") == 0
             # the kept mass straddles top_p like the reference's
             p = O.scaled_softmax_f16(z[f"wor{i}/logits"], 0.6).astype(np.float64)
             assert (np.where(np.isinf(got), 0, p).sum(1) >= min(tp, p.max(1).min()) - 2e-3).all()
+    assert exact >= 5          # most rows have no tie at the cut and match token for token (5 of 8 on the committed rows)

@@ -80,9 +80,10 @@ def test_get_sampling_logits(RU, V, gain, top_p, T):
     logits = (torch.randn(4, V) * gain).half()
     want = RU.get_sampling_logits(logits.clone(), top_p, T).numpy()
     got = O.top_p_filter(logits.numpy(), top_p, T)
-    kept_equal = np.isinf(got) == np.isinf(want)
-    assert (~kept_equal).sum(axis=1).max() <= 6                                   # ties / a rounding boundary at the cut
-    assert np.array_equal(got[kept_equal & ~np.isinf(got)], want[kept_equal & ~np.isinf(want)])
+    from helpers import assert_top_p_equal_up_to_ties
+    # identical up to the identity of equal-logit tokens at the cut (torch's unstable CPU sort of fp16); a probability that
+    # differs from torch's by the last fp32 ulp of exp() could move the cut as well -- not observed on these rows
+    assert_top_p_equal_up_to_ties(logits.numpy(), got, want, f"V={V} P={top_p}")
     p = O.scaled_softmax_f16(logits.numpy(), T).astype(np.float64)
     assert (np.where(np.isinf(got), 0, p).sum(1) >= min(top_p, p.max(1).min()) - 2e-3).all()
 

@@ -56,8 +56,14 @@ def test_verify_probe_matches_oracle_on_star_trees(ops, seed):
     from sequoia_amd.native import SQ_VERIFY_GATHER_FIRST
     ops.verify_probe(dev(tl), d_dl, d_tok, dev(r32), dev(off), dev(ids), w + 1, gt, T, 424242 | SQ_VERIFY_GATHER_FIRST, ws, res)
     r = res.cpu().numpy()
-    if min(abs(m) for m in margins) < 1e-3 and r[0] != want["accept_len"]:
-        pytest.skip("margin-limited decision")
+    if r[0] != want["accept_len"]:
+        # fresh random inputs: the walk of a star tree is one level of decisions; the kernel may leave the oracle only at
+        # the decision where the two paths part, and only if that decision's own margin is inside one fp16 ulp of p
+        from helpers import note_escape, split_margin
+        m = split_margin(succ, gt, want["slots"], [int(x) for x in r[8:8 + r[1]]], margins)
+        assert m is not None and abs(m) < 1e-3, f"seed {seed}: paths split at a decision with margin {m}"
+        note_escape(f"test_verify_probe_matches_oracle_on_star_trees seed={seed}", m)
+        return
     assert r[0] == want["accept_len"] and r[1] == want["n_tree"] and r[3] == want["terminal"]
     assert (r[6] - 1 if r[1] else -1) == (want["last_node"] - 1 if want["n_tree"] else -1)
     assert np.array_equal(d_tok.cpu().numpy()[:want["accept_len"]], o_tok[:want["accept_len"]])

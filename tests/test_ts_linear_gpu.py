@@ -74,7 +74,10 @@ def test_linear_ts_bit_exact_on_order_independent_operands(m, n, k, tiles, split
 
 @pytest.mark.parametrize("m,inter,k,tiles,out_frag", [(16, 64, 128, 2, False), (34, 3072, 768, 96, True), (48, 11008, 4096, 230, True),
                                                       (64, 1024, 512, 32, False), (128, 2048, 1024, 64, True), (100, 5504, 256, 172, True),
-                                                      (128, 11008, 512, 230, True), (96, 3072, 768, 64, False)])
+                                                      (128, 11008, 512, 230, True), (96, 3072, 768, 64, False),
+                                                      # 4 gate+up units per workgroup (8 MFMA column tiles): the 13B plans
+                                                      (64, 13824, 512, 216, True), (128, 13824, 256, 216, True), (17, 1024, 256, 16, False),
+                                                      (128, 11008, 512, 172, True), (100, 2048, 128, 32, False)])
 def test_linear_ts_swiglu_epilogue(m, inter, k, tiles, out_frag):
     ops = _ops()
     rng = np.random.default_rng(inter + m)
@@ -259,13 +262,14 @@ def test_autotune_returns_a_usable_plan_and_never_runs_inside_a_capture():
 def test_plan_candidates_respect_kernel_limits():
     from sequoia_amd.Engine.ts_linear import candidates
     for n_out, k, silu, m in [(12288, 4096, False, 128), (11008, 4096, True, 48), (11008, 4096, True, 128), (768, 3072, False, 34),
-                              (32000, 768, False, 1)]:
+                              (32000, 768, False, 1), (15360, 5120, False, 64), (13824, 5120, True, 64), (28672, 8192, True, 129)]:
         for tiles, splits in candidates(n_out, k, silu, m, allow_split=True):
             # a SwiGLU layer with K-splits runs as a plain [2 n_out] x k projection (+ sq_silu_mul_slabs_f16)
             plain = not silu or splits > 1
             units = (2 * n_out if silu and splits > 1 else n_out) // 16
             per = (units + tiles - 1) // tiles
-            assert per <= ((6 if m > 64 else 4) if plain else 3)
+            wide = 8 if (not silu and m <= 128 and n_out >= 8192) else (6 if m > 64 else 4)
+            assert per <= (wide if plain else (4 if m <= 128 else 3))
             assert k // 32 >= splits * 8
 
 

@@ -34,7 +34,9 @@ int main(int argc, char** argv) {
         if (only && !strstr(only, sh.name)) continue;
         const int wrows = sh.silu ? 2 * sh.n_out : sh.n_out;
         const size_t wbytes = (size_t)wrows * sh.k * 2;
-        const int nbuf = (int)((640ull << 20) / wbytes) + 1;
+        // TS_NBUF=1: the same weight buffer every launch (hot: whatever the 256 MiB Infinity Cache keeps of it is re-read from
+        // there) -- the cold / hot difference bounds what a run-ahead prefetch into the Infinity Cache could buy
+        const int nbuf = getenv("TS_NBUF") ? atoi(getenv("TS_NBUF")) : (int)((640ull << 20) / wbytes) + 1;
         std::vector<_Float16> hw((size_t)wrows * sh.k);
         fill_half(hw, 0.05f);
         std::vector<void*> dws(nbuf);
