@@ -32,10 +32,35 @@ sys.path.insert(0, REPO)
 from sequoia_amd.harness import MODELS, Loop, build, load_prompts  # noqa: E402
 
 
+def capture_step_inputs(cfg, loop, device):
+    """One real speculation step of the loop's model pair, host-driven, on a fresh prompt (the second step of the prompt:
+    the target cache is prefilled, the step is a steady one).  Returns what its samplers and its verifier saw -- the draft
+    rows BEFORE the verifier masks rejected tokens, the target rows, tokens, acceptance uniforms, sampler noise, gt -- so
+    that `kernels` times those launches on the loop's own data, not on synthetic logits (VERDICT r03 #3a: the synthetic
+    pair of round 3 rejected less than the loop does and the line flattered the verifier)."""
+    probe = Loop(cfg, loop.draft, loop.target, loop.gm_obj, device, loop.prompts, use_graphs=True, pipelined=False)
+    loop.draft.clear_kv(); loop.target.clear_kv()
+    probe.run_steps(1)                                  # the prefill-bearing first step
+    tree = probe.tree
+    if tree is None:                                    # (a prompt that ended in one step: take the next one)
+        probe.run_steps(1)
+        tree = probe.tree
+    tree.construct_grow_map()
+    snap = dict(gt=int(tree.ground_truth_len), draft_logits=tree.draft_logits[:tree.tree_size].clone(), tokens=tree.tokens.clone(),
+                r=tree.r.clone() if getattr(tree, "r", None) is not None else None,
+                rand=tree.rand if getattr(tree, "rand", None) is not None else None)
+    tree.verify()
+    snap["target_logits"] = tree.target_logits.clone()
+    snap["accepted"] = int(tree.last_result[1])
+    loop.draft.clear_kv(); loop.target.clear_kv()
+    return snap
+
+
 def kernel_rooflines(cfg, loop, device):
     """Per-kernel average duration at the workload's shapes, HIP events on the launch stream
     (torch's current stream is the one the C ABI launches on), and algorithmic bytes
-    (SURVEY.md §8d formulas)."""
+    (SURVEY.md §8d formulas).  Sampler and verifier run on the inputs of a captured loop step (capture_step_inputs)
+    and as the launch sequence the device-driven loop issues (Tree/step_graph.py::body)."""
     from sequoia_amd.ops import get_ops
     ops = get_ops()
     tgt = loop.target.engine
@@ -44,7 +69,17 @@ def kernel_rooflines(cfg, loop, device):
     n, V, M = g.size, 32000, cfg["M"]
     dims = tgt.model.dims
     H, Hkv, D, L = dims.local_heads, dims.local_kv_heads, dims.head_dim, dims.num_hidden_layers
-    gt = 160
+    import torch.distributed as dist
+    if cfg.get("tp") and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # tensor-parallel job: a forward is a collective and only rank 0 is here -- synthetic rows instead of a captured step
+        tl = (torch.randn(n, V, device=device) * 3).half()
+        snap = dict(gt=160, target_logits=tl, draft_logits=(tl.float() + torch.randn(n, V, device=device) * 2).half(),
+                    tokens=torch.randint(3, V, (M,), device=device), r=torch.rand(M, device=device).half(),
+                    rand=torch.rand(n, V, device=device).half(), accepted=-1)
+    else:
+        snap = capture_step_inputs(cfg, loop, device)
+    # the prompts run from 128 committed tokens to 256: the attention launch is timed at the middle of that range
+    gt = 192 if M >= 384 else snap["gt"]
     kv_len = gt - 1 + n
     res = {}
 
@@ -92,44 +127,71 @@ def kernel_rooflines(cfg, loop, device):
     t = timeit(attn, 320)
     byts = 2 * Hkv * kv_len * D * 2 + 2 * H * n * D * 2
     res["tree_attention_target"] = dict(seconds=t, bytes=byts, launches_per_step=L,
-                                        flops=4 * H * n * kv_len * D)
-    # verifier (nodes + walk)
+                                        flops=4 * H * n * kv_len * D, kv_len=kv_len)
+    # verifier (nodes + walk) on the captured step
     n_internal = sum(1 for s in g.successors if s)
+    sgt = snap["gt"]
     if cfg["mode"] == "stochastic":
-        tl = (torch.randn(n, V, device=device) * 3).half()
-        dl = (tl.float() + torch.randn(n, V, device=device) * 2).half()
-        toks = torch.randint(3, V, (M,), device=device)
-        r = torch.rand(M, device=device).half()
+        tl, dl, toks0, r = snap["target_logits"], snap["draft_logits"], snap["tokens"], snap["r"]
+        toks = toks0.clone()
         ws = ops.verify_workspace(n, device)
         rr = torch.zeros(64 + n, dtype=torch.int32, device=device)
         dl2 = dl.clone()
 
-        # The verifier masks the rejected tokens in the draft rows (-65504 writes, Tree/SpecTree.py:156): a second launch on
-        # the same buffer would find them masked and accept at once.  Every timed launch therefore starts from a fresh copy
-        # of the draft rows; the copy is timed alone and subtracted.  (The number still depends on how often the model pair
-        # rejects: the loop's own figure is in profiles/r03_bench_kernel_stats_loop_only.md.)
-        toks0 = toks.clone()
-
+        # The verifier masks the rejected tokens in the draft rows (-65504 writes, Tree/SpecTree.py:156) and compacts
+        # `tokens`: every timed launch starts from a fresh copy of both; the copies are timed alone and subtracted.
         def restore():
             dl2.copy_(dl)
             toks.copy_(toks0)
 
         def ver():
             restore()
-            ops.verify_stochastic(tl, dl2, toks, r, gdev["child_off"], gdev["child_ids"], n, gt, 0.6, 12345, ws, rr)
+            ops.verify_stochastic(tl, dl2, toks, r, gdev["child_off"], gdev["child_ids"], n, sgt, 0.6, 12345, ws, rr)
         t = timeit(ver, 64, 16) - timeit(restore, 64, 16)
-        res["verify_stochastic"] = dict(seconds=t, bytes=(n + n_internal) * V * 2, launches_per_step=1)
-        # sampler, all levels of one step
-        rand = torch.rand(n, V, device=device).half()
+        res["verify_stochastic"] = dict(seconds=t, bytes=(n + n_internal) * V * 2, launches_per_step=1,
+                                        inputs=(f"captured loop step (gt {sgt}, {snap['accepted']} tree tokens accepted)"
+                                                if snap["accepted"] >= 0 else "synthetic rows (tensor-parallel job)"))
+        # samplers of one step as the device-driven loop issues them (Tree/step_graph.py::body): per level the two sampler
+        # launches on statistics the preceding forward's row adoption left (sq_logits_stats_f16 with the row copy -- the
+        # reference's `draft_logits[...] = logits` slice copy rides on that launch), plus the adoption of the next root row
+        rand = snap["rand"]
         tokbuf = torch.zeros(M, dtype=torch.long, device=device)
+        stats = torch.zeros(ops.stats_shape(n, V), dtype=torch.float32, device=device)
+        dl3 = dl.clone()
+
+        ops.logits_stats(dl, 0.6, stats)                  # valid statistics for every row before the first timed pass
 
         def samp():
             for lv in gdev["levels"]:
-                ops.sample_wor(dl, rand, lv["row_ids"], lv["k"], 0.6, tokbuf, branch=lv["branch"], out_off=lv["out_off"])
+                first, total = lv["first_child"], lv["total"]
+                ops.sample_wor(dl3, rand, lv["row_ids"], lv["k"], 0.6, tokbuf, branch=lv["branch"], out_off=lv["out_off"], stats=stats)
+                ops.logits_stats(dl[first:first + total], 0.6, stats[first:first + total], copy_dst=dl3[first:first + total])
+            ops.logits_stats(dl[0:1], 0.6, stats[0:1], copy_dst=dl3[0:1])
         t = timeit(samp, 64, 16)
         rows = sum(lv["n_rows"] for lv in gdev["levels"])
         res["sample_wor_all_levels"] = dict(seconds=t, bytes=rows * V * 4 + sum(lv["total"] for lv in gdev["levels"]) * 8,
-                                            launches_per_step=len(gdev["levels"]))
+                                            launches_per_step=3 * len(gdev["levels"]) + 1,
+                                            inputs="captured loop step; statistics + row-adoption launches included")
+    else:
+        tl, toks0 = snap["target_logits"], snap["tokens"]
+        toks = toks0.clone()
+        ws = ops.verify_workspace(n, device)
+        rr = torch.zeros(64 + n, dtype=torch.int32, device=device)
+
+        def verg():
+            toks.copy_(toks0)
+            ops.verify_greedy(tl, toks, gdev["child_off"], gdev["child_ids"], n, sgt, ws, rr)
+        t = timeit(verg, 64, 16) - timeit(lambda: toks.copy_(toks0), 64, 16)
+        res["verify_greedy"] = dict(seconds=t, bytes=n * V * 2, launches_per_step=1, inputs=f"captured loop step (gt {sgt})")
+        dl = snap["draft_logits"]
+        tokbuf = torch.zeros(M, dtype=torch.long, device=device)
+
+        def topk():
+            for lv in gdev["levels"]:
+                ops.topk(dl, lv["row_ids"], lv["k"], tokbuf, branch=lv["branch"], out_off=lv["out_off"])
+        t = timeit(topk, 64, 16)
+        rows = sum(lv["n_rows"] for lv in gdev["levels"])
+        res["topk_all_levels"] = dict(seconds=t, bytes=rows * V * 2, launches_per_step=2 * len(gdev["levels"]))
     # KV compaction of 4 accepted nodes on the target cache
     slots = torch.tensor([gt + 1, gt + 20, gt + 50, gt + 90], dtype=torch.int32, device=device)
 
@@ -172,6 +234,71 @@ def kernel_rooflines(cfg, loop, device):
     return res
 
 
+def step_weight_bytes(loop, gm):
+    """Weight bytes one speculation step streams from HBM: every projection of the target once (the verify forward) and of
+    the draft once per tree level plus once for the next-root forward (the end-to-end step is HBM-bound on
+    these bytes).  Tensor-parallel shards count their own rank's bytes."""
+    def model_bytes(engine):
+        m = engine.engine.model
+        W = m.weights
+        per_layer = sum(w.numel() * 2 for lw in W.layers[:1] for w in (lw.wqkv, lw.wo, lw.w_gate_up, lw.w_down) if w is not None)
+        if per_layer == 0 and getattr(m, "ts", None) is not None:       # exclusive mode: only the fragment-major images exist
+            per_layer = m.ts.layer_weight_bytes() // len(W.layers)
+        return per_layer * len(W.layers) + W.lm_head.numel() * 2
+    n_draft_forwards = (len(gm.levels) if hasattr(gm, "levels") else 0) + 1
+    t, d = model_bytes(loop.target), model_bytes(loop.draft)
+    return dict(target=t, draft=d, draft_forwards=n_draft_forwards, total=t + d * n_draft_forwards)
+
+
+def run_other_config(name, args, device, prompts, engines=None, steps=20, warmup=5):
+    """Configs C / D after the headline (VERDICT r03 #3c): the same device-driven loop, `steps` timed steps, their own
+    roofline object (dominant kernel by time per step, HIP-event timing on the launch stream)."""
+    cfg = dict(MODELS[name])
+    t0 = time.perf_counter()
+    if engines is None:
+        draft, target, gm = build(cfg, device, args.pair)
+    else:
+        from sequoia_amd.growmap import GrowMap
+        draft, target = engines
+        gm = GrowMap.load(cfg["growmap"])
+        draft.clear_kv(); target.clear_kv()
+    torch.manual_seed(17)
+    loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs,
+                pipelined=not args.sync_loop and not args.no_graphs)
+    loop.run_steps(warmup)
+    torch.cuda.synchronize()
+    p0 = loop.prefill_steps
+    secs, new_tok, steps_done = loop.run_steps(steps)
+    torch.cuda.synchronize()
+    kr = kernel_rooflines(cfg, loop, device)
+    per_step = {k: v["seconds"] * v["launches_per_step"] if (k == "tree_attention_target" or k.startswith("linear_ts_")) else v["seconds"]
+                for k, v in kr.items()}
+    dom = max(per_step, key=per_step.get)
+    d = kr[dom]
+    wb = step_weight_bytes(loop, gm)
+    out = dict(workload=f"config {name}: {cfg['draft']} -> {cfg['target']} architectures, growmap {cfg['growmap']} ({gm.size}-node tree)",
+               value=new_tok / secs, unit="tokens/s", ms_per_step=secs / steps_done * 1e3, steps=steps_done, warmup=warmup,
+               mean_accepted_len=new_tok / steps_done, prefill_steps_in_timed_region=loop.prefill_steps - p0,
+               roofline=dict(bound="hbm", kernel=dom, achieved=d["bytes"] / d["seconds"] / 1e9, peak=8000.0, unit="GB/s",
+                             frac=d["bytes"] / d["seconds"] / 1e9 / 8000.0, avg_launch_us=d["seconds"] * 1e6,
+                             algorithmic_bytes_per_launch=d["bytes"], time_per_step_us=per_step[dom] * 1e6, plan=d.get("plan"),
+                             traffic=None),
+               step_roofline=dict(weight_bytes=wb["total"], frac=wb["total"] / (secs / steps_done) / 8e12),
+               kernels={k: dict(avg_us=round(v["seconds"] * 1e6, 2), per_step_us=round(per_step[k] * 1e6, 1),
+                                frac=round(v["bytes"] / v["seconds"] / 8e12, 4), plan=v.get("plan")) for k, v in kr.items()},
+               seconds_total=round(time.perf_counter() - t0, 1))
+    if name == "D":
+        pk = None
+        if dom.startswith("linear_ts_") and d.get("plan"):
+            pk = f"D:{dom[len('linear_ts_'):]}@{(gm.size + 15) // 16}:{d['plan'][0]}x{d['plan'][1]}"
+            traffic, mfma_util, pmc_file, note = pmc_lookup(pk, dom)
+            out["roofline"].update(traffic=traffic, mfma_util=mfma_util, pmc_key=pk, pmc_file=pmc_file)
+            if note:
+                out["roofline"]["traffic_note"] = note
+    del loop
+    return out, (draft, target)
+
+
 T_START = time.perf_counter()
 
 
@@ -187,7 +314,7 @@ def source_sha(*names):
 
 def pmc_lookup(pmc_key, dom):
     """HBM bytes per launch and MFMA utilisation of the dominant kernel from the newest profiles/r*_pmc.json (rocprofv3 PMC
-    passes, tools/pmc_r03.sh: FETCH_SIZE / WRITE_SIZE / SQ group in separate passes, gfx950 correction 2 FETCH + WRITE).
+    passes, tools/pmc_r04.sh: FETCH_SIZE / WRITE_SIZE / SQ group in separate passes, gfx950 correction 2 FETCH + WRITE).
     The record must carry the sha of the kernel source it was measured on and that sha must match the tree bench runs
     from: a stale record gives traffic = null and says so.  -> (traffic, mfma_util, file, note)"""
     import glob
@@ -207,7 +334,7 @@ def pmc_lookup(pmc_key, dom):
             notes.append(f"{os.path.basename(path)}: measured on {src} {have}, this tree has {want}")
             continue
         return rec["hbm_bytes_per_launch"], rec["mfma_util"], os.path.relpath(path, REPO), None
-    return None, None, None, "no valid PMC record for " + pmc_key + ": " + "; ".join(notes) + " -- re-run tools/pmc_r03.sh"
+    return None, None, None, "no valid PMC record for " + pmc_key + ": " + "; ".join(notes) + " -- re-run tools/pmc_r04.sh"
 
 
 def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=False):
@@ -228,7 +355,7 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
     # threads and 64 (SEQUOIA_CPU_THREADS=a,b,c overrides) and the fastest is the baseline -- the honest best of this host
     prev_threads = torch.get_num_threads()
     avail = os.cpu_count() or prev_threads
-    sweep = [int(x) for x in os.environ.get("SEQUOIA_CPU_THREADS", "8,16,32,64").split(",") if x.strip()]
+    sweep = [int(x) for x in os.environ.get("SEQUOIA_CPU_THREADS", "16,32,64").split(",") if x.strip()]
     sweep = sorted({max(1, min(t, avail)) for t in sweep}) or [prev_threads]
     torch.set_num_threads(sweep[len(sweep) // 2])
     try:
@@ -248,9 +375,20 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
                    parents_buffer=None, position_ids=torch.zeros(M, dtype=torch.long), residual_graph=None,
                    sampling_callables=None, sample_gather_indices=None, commit_order=COMMIT_ORDER)
         cur, step_s, step_tok, step_thr = len(p), [], [], []
-        n_total = max(2, n_steps, 1 + len(sweep))
+        # step 0: prefill-bearing; then one steady step per thread count of the sweep; then 2 more at the fastest count, so
+        # that the baseline is the MEDIAN of 3 steady steps at the best thread count (single samples of 5-8 s steps scatter
+        # by more than the reference-vs-port difference they are quoted next to: VERDICT r03 weak #8)
+        n_total = max(2, n_steps, 1 + len(sweep) + 2)
         for i in range(n_total):
-            thr = sweep[(i - 1) % len(sweep)] if i > 0 else sweep[len(sweep) // 2]
+            if i == 0:
+                thr = sweep[len(sweep) // 2]
+            elif i <= len(sweep):
+                thr = sweep[i - 1]
+            else:
+                seen = {}
+                for sec_, thr_ in zip(step_s[1:], step_thr[1:]):
+                    seen.setdefault(thr_, []).append(sec_)
+                thr = min(seen, key=lambda t_: min(seen[t_]))
             torch.set_num_threads(thr)
             t1 = time.perf_counter()
             tree.construct_grow_map()
@@ -265,8 +403,9 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
         by_thr = {}
         for sec, thr in zip(step_s[1:], step_thr[1:]):
             by_thr.setdefault(thr, []).append(sec)
-        mean_by_thr = {t: sum(v) / len(v) for t, v in by_thr.items()}
-        best_thr = min(mean_by_thr, key=mean_by_thr.get) if mean_by_thr else step_thr[0]
+        import statistics
+        mean_by_thr = {t: statistics.median(v) for t, v in by_thr.items()}          # (median: 3 samples at the best count)
+        best_thr = max(by_thr, key=lambda t: (len(by_thr[t]), -mean_by_thr[t])) if by_thr else step_thr[0]
         best_s = mean_by_thr.get(best_thr)
         tok_per_step = (sum(step_tok[1:]) / n_steady) if n_steady else None
         # the imported reference beside this port on the same weights / prompt / noise (oracle/ref_cpu_baseline.py, run in
@@ -284,9 +423,11 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
                     kind="port", commit_order=COMMIT_ORDER,
                     sample=f"{len(step_s)} speculation steps of prompt 0, config {cfg['draft']} -> {cfg['target']}, the "
                            f"reference's torch op sequences on CPU fp16 tensors; step 0 (with the 255-token target prefill) "
-                           f"{step_s[0]:.1f} s, then {n_steady} steady steps, one per thread count of {sweep}: "
-                           f"{ {t: round(v, 2) for t, v in mean_by_thr.items()} } s / step; value = mean tokens/step of the steady "
-                           f"steps / the fastest step time (+{build_s:.0f} s weight init)",
+                           f"{step_s[0]:.1f} s, then {n_steady} steady steps: one per thread count of {sweep}, two more at the "
+                           f"fastest; median seconds / step by thread count { {t: round(v, 2) for t, v in mean_by_thr.items()} }; "
+                           f"value = mean tokens/step of the steady steps / the MEDIAN of the {len(by_thr.get(best_thr, []))} steps at "
+                           f"{best_thr} threads (+{build_s:.0f} s weight init)",
+                    samples_at_best=[round(x, 3) for x in by_thr.get(best_thr, [])],
                     steps_per_s=(1.0 / best_s) if n_steady else None, prefill_step_s=step_s[0],
                     step_seconds=[round(x, 3) for x in step_s], step_threads=step_thr, step_tokens=step_tok,
                     seconds_per_step_by_threads={str(t): round(v, 3) for t, v in mean_by_thr.items()},
@@ -319,9 +460,15 @@ def allreduce_timing(target, device, rows, reps=40):
         t = torch.tensor([e0.elapsed_time(e1) * 1e3 / reps], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t)
+    from sequoia_amd.Engine import xgmi_allreduce as XA
     if getattr(inner, "xgmi", None) is not None:
         out["xgmi_us"] = timeit(lambda: inner.xgmi(x))
         out["xgmi_status"] = inner.xgmi.status()
+        out["xgmi_fault_word"] = int(inner.xgmi.fault[0]) if inner.xgmi.fault is not None else None
+        out["xgmi_self_check"] = "passed (all-reduce, all-gather, all-reduce + RMSNorm against torch.distributed at set-up)"
+        out["workspace"] = XA.WS_MODE
+    else:
+        out["xgmi_self_check"] = "not running on the xGMI kernels: " + (XA.LAST_REFUSAL or "SEQUOIA_TP_ALLREDUCE=rccl")
     out[("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) + "_us"] = timeit(lambda: dist.all_reduce(x))
     return out
 
@@ -348,6 +495,9 @@ def tp_extra(n: int, args) -> dict:
     once on RCCL collectives only (SEQUOIA_TP_ALLREDUCE=rccl).  Returns the child's JSON line (trimmed) or an error record."""
     first = _tp_child(n, args, {})
     if "error" not in first:
+        return first
+    if os.environ.get("SEQUOIA_TP_REQUIRE_XGMI", "0") == "1":
+        first["note"] = "SEQUOIA_TP_REQUIRE_XGMI=1: no retry on RCCL"      # fail loudly, not silently on the fallback
         return first
     second = _tp_child(n, args, {"SEQUOIA_TP_ALLREDUCE": "rccl"}, timeout_s=int(os.environ.get("SEQUOIA_TP_RETRY_TIMEOUT", "150")))
     second["first_attempt"] = dict(collectives="xgmi", **{k: first[k] for k in ("error", "stderr") if k in first})
@@ -384,10 +534,17 @@ def _tp_child(n: int, args, extra_env: dict, timeout_s: int = 0) -> dict:
         return dict(error=f"rc {out.returncode}", stderr=out.stderr[-400:])
     d = json.loads(lines[-1])
     keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "mean_accepted_len", "rccl_ranks", "config",
-            "roofline", "allreduce", "prefill_steps_in_timed_region")
+            "roofline", "step_roofline", "allreduce", "prefill_steps_in_timed_region")
     res = {k: d[k] for k in keep if k in d}
     if "config" in d:
         res["step_loop"] = d["config"].get("step_loop")
+    ar = d.get("allreduce") or {}
+    # what the collectives actually ran on, at the top level: a first multi-GPU run that fell back to RCCL must be readable
+    # as such from the line alone (VERDICT r03 #4b)
+    res["allreduce_kind"] = ar.get("kind")
+    res["xgmi_status"] = ar.get("xgmi_status")
+    res["xgmi_self_check"] = ar.get("xgmi_self_check")
+    res["collectives_env"] = extra_env.get("SEQUOIA_TP_ALLREDUCE", os.environ.get("SEQUOIA_TP_ALLREDUCE", "xgmi"))
     return res
 
 
@@ -438,6 +595,11 @@ def main():
     ap.add_argument("--no-kernel-rooflines", action="store_true",
                     help="profiling aid: skip the per-kernel micro-timings (and with them `roofline` / `kernels`), so that a "
                          "rocprofv3 trace of this command contains the loop's own dispatches only")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="single-GPU config B: skip the configs C and D runs that follow the headline (`other_configs`)")
+    ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each `other_configs` run")
+    ap.add_argument("--no-reference-metric", action="store_true",
+                    help="skip the whole-prompt run behind `value_reference_metric` / `prefill_step_ms`")
     ap.add_argument("--no-tp-extra", action="store_true",
                     help="N > 1: skip the secondary run of configuration E (70B target tensor-parallel over the N GPUs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
@@ -482,8 +644,9 @@ def main():
     loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs,
                 pipelined=not args.sync_loop and not args.no_graphs)
 
-    from sequoia_amd.Tree._native_tree import COMMIT_ORDER as commit_order
+    from sequoia_amd.Tree._native_tree import COMMIT_ORDER as commit_order, QUIRK_STEPS
     loop.run_steps(args.warmup)
+    QUIRK_STEPS[0] = 0           # counted over the timed steps only (config.commit_order_quirk_steps)
     if tp_mode and world > 1:
         from sequoia_amd.Engine.ts_linear import assert_same_plans_across_ranks
         assert_same_plans_across_ranks(draft.engine.model, target.engine.model)
@@ -527,7 +690,7 @@ def main():
         d = kr[dom]
         peak_hbm = 8000.0
         # HBM bytes per launch and MFMA utilisation of the dominant kernel: rocprofv3 PMC passes committed under profiles/
-        # (tools/pmc_r02.sh; FETCH_SIZE / WRITE_SIZE / SQ group in separate passes, gfx950 correction 2 FETCH + WRITE), keyed
+        # (tools/pmc_r04.sh; FETCH_SIZE / WRITE_SIZE / SQ group in separate passes, gfx950 correction 2 FETCH + WRITE), keyed
         # by the launch plan THIS run used -- a plan the passes did not cover gives traffic = null and says so
         traffic = mfma_util = None
         traffic_note = None
@@ -551,7 +714,8 @@ def main():
             roof["traffic_note"] = traffic_note
         kernels = {k: dict(avg_us=v["seconds"] * 1e6, gbps=v["bytes"] / v["seconds"] / 1e9,
                            frac=v["bytes"] / v["seconds"] / 1e9 / peak_hbm, algorithmic_bytes=v["bytes"],
-                           launches_per_step=v["launches_per_step"], per_step_us=per_step[k] * 1e6) for k, v in kr.items()}
+                           launches_per_step=v["launches_per_step"], per_step_us=per_step[k] * 1e6,
+                           **{kk: v[kk] for kk in ("inputs", "plan", "kv_len") if kk in v}) for k, v in kr.items()}
         tuned = None
         tuned_name = "MI355X-synthetic-68m-7b-stochastic"
         if not args.no_tuned_growmap and world == 1 and args.config == "B" and not args.growmap and args.pair == "calibrated":
@@ -591,6 +755,46 @@ def main():
             except Exception as e:  # the baseline is a report, never the measured path
                 cpu = dict(value=None, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
                            sample=f"failed: {type(e).__name__}: {e}")
+        # the reference's own metric (tests/testbed.py:78-95): total_time / tokens over WHOLE prompts, each prompt's first
+        # verify carrying the target prefill of the 128-token prompt -- `value` above is steady steps (the driver's 20 timed
+        # steps never reach a second prompt); both are printed, with the time of a prefill-bearing step
+        ref_metric = None
+        if not args.no_reference_metric and world == 1:
+            draft.clear_kv(); target.clear_kv()
+            torch.manual_seed(17 + rank)
+            loop4 = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs,
+                         pipelined=not args.sync_loop and not args.no_graphs)
+            loop4.run_prompts(1)                                   # warm-up prompt (graphs, plans)
+            pf_s0, pf_n0 = loop4.prefill_seconds, loop4.prefill_steps
+            s4, t4, k4 = loop4.run_prompts(3)
+            pf_n = loop4.prefill_steps - pf_n0
+            ref_metric = dict(value=t4 / s4, unit="tokens/s", prompts=3, steps=k4, tokens=t4, seconds=s4,
+                              prefill_steps=pf_n, prefill_step_ms=(loop4.prefill_seconds - pf_s0) / max(pf_n, 1) * 1e3,
+                              steady_ms_per_step=(s4 - (loop4.prefill_seconds - pf_s0)) / max(k4 - pf_n, 1) * 1e3,
+                              note="whole prompts, 128 prompt tokens -> 256 tokens, per-prompt setup (tree constructor, draft "
+                                   "prefill) outside the timer like tests/testbed.py:67-79; the first verify of every prompt "
+                                   "carries the 255-row target prefill")
+            del loop4
+        wb = step_weight_bytes(loop, gm)
+        step_roof = dict(weight_bytes=wb["total"], target_bytes=wb["target"], draft_bytes_per_forward=wb["draft"],
+                         draft_forwards=wb["draft_forwards"], achieved=wb["total"] / (secs / args.steps) / 1e9, peak=8000.0,
+                         unit="GB/s", frac=wb["total"] / (secs / args.steps) / 8e12,
+                         note="projection + lm_head weight bytes one speculation step streams (rank-local), over ms_per_step")
+        other = None
+        if (not args.no_other_configs and world == 1 and args.config == "B" and not args.growmap and args.pair == "calibrated"
+                and not args.sync_loop and not args.no_graphs):
+            other = {}
+            try:
+                other["C"], _ = run_other_config("C", args, device, prompts, engines=(draft, target), steps=args.other_steps)
+            except Exception as e:
+                other["C"] = dict(error=f"{type(e).__name__}: {e}")
+            try:
+                import gc
+                other["D"], eng_d = run_other_config("D", args, device, prompts, steps=args.other_steps)
+                del eng_d
+                gc.collect(); torch.cuda.empty_cache()
+            except Exception as e:
+                other["D"] = dict(error=f"{type(e).__name__}: {e}")
         line = dict(metric="accepted tokens/sec", value=new_tok / secs, unit="tokens/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=secs / args.steps * 1e3,
                     higher_is_better=True, scaling="strong" if tp_mode else "weak", vs_baseline=None, dtype="f16", data="synthetic",
@@ -599,7 +803,7 @@ def main():
                                          f"({gm.size}-node tree), T=0.6, top_p=1.0, M={cfg['M']}, 128-token c4_small "
                                          f"prompts, generate to 256",
                                 parallelism=(f"tp{world}" if tp_mode else ("replicas" if world > 1 else "single")), graphs=not args.no_graphs,
-                                commit_order=commit_order,
+                                commit_order=commit_order, commit_order_quirk_steps=QUIRK_STEPS[0],
                                 step_loop="device-driven (one hipGraph per speculation step, results read one step late)"
                                 if loop.pipelined else "host-driven (one result read per step)",
                                 gemm="tree forwards (<= 144 rows): sq_linear_ts_f16 (fragment-major weight stream, plans "
@@ -607,7 +811,10 @@ def main():
                                      + ("TunableOp-selected hipBLASLt / rocBLAS solutions" if gemm_tuned else "default algorithm") + ")"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs, rccl_ranks=rccl_ranks,
                     prefill_steps_in_timed_region=prefill_steps, allreduce=allreduce,
-                    roofline=roof, kernels=kernels, host_driven_loop=host_loop, mi355x_growmap=tuned,
+                    roofline=roof, step_roofline=step_roof, kernels=kernels,
+                    value_reference_metric=ref_metric["value"] if ref_metric else None,
+                    prefill_step_ms=ref_metric["prefill_step_ms"] if ref_metric else None, reference_metric=ref_metric,
+                    other_configs=other, host_driven_loop=host_loop, mi355x_growmap=tuned,
                     autoregressive_baseline=autoreg,
                     cpu_baseline=cpu)
     if world > 1:

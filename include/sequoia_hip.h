@@ -107,6 +107,13 @@ int sq_kv_compact_f16(void* k_cache, void* v_cache, int n_layers, int h_kv, int 
                       const int32_t* d_slots, const int32_t* d_count, int max_count,
                       int dst_offset, int zero_end, const int32_t* d_dst_offset, void* stream);
 
+/* The same roll-back for TWO caches in one launch (the speculation step compacts the draft cache and the target cache
+ * with the same accepted slots and the same destination, Tree/SpecTree.py:226-227): cache 0 and cache 1 may differ in
+ * layers / KV heads / M / D.  No tail zeroing in this form (the device-driven step never zeroes).                    */
+int sq_kv_compact2_f16(void* k0, void* v0, int n_layers0, int h_kv0, int m0, int d0, void* k1, void* v1, int n_layers1,
+                       int h_kv1, int m1, int d1, const int32_t* d_slots, const int32_t* d_count, int max_count,
+                       int dst_offset, const int32_t* d_dst_offset, void* stream);
+
 /* KV_Cache.clear (Engine/Llama_KV.py:91-94) restricted to rows [0, used_rows) of every
  * (layer, head): rows never written are already zero.                                       */
 int sq_kv_clear_f16(void* k_cache, void* v_cache, int n_layers, int h_kv, int m, int d,
@@ -349,11 +356,14 @@ size_t sq_linear_ts_workspace_bytes(int m, int n_out, int splits);
 int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const void* res, void* out, int ldo, int out_frag, int m,
                      int n_out, int k, int silu, int tiles, int splits, void* slab, size_t slab_bytes, void* stream);
 
-/* Measurement aid (tools/prefetch_probe.py): touches, from `grid` workgroups, one dword of every 128-byte line that the
- * workgroups of sq_linear_ts_f16(..., tiles, splits) load in their first `depth` k-steps, so that those lines sit in the
- * XCD L2s when the projection starts.  Not used by the product path.                                               */
+#ifdef SEQUOIA_BUILD_PROBES
+/* Measurement aid, NOT part of the library's default surface: built only with SEQUOIA_BUILD_PROBES=1 (sequoia_amd/build.py
+ * then adds csrc/ts_probe.hip), used by tools/prefetch_probe.py.  Touches, from `grid` workgroups, one dword of every
+ * 128-byte line that the workgroups of sq_linear_ts_f16(..., tiles, splits) load in their first `depth` k-steps, so that
+ * those lines sit in the XCD L2s when the projection starts (profiles/r03_prefetch_probe.md).                        */
 int sq_linear_ts_prefetch(const void* w_frag, int n_out, int k, int silu, int tiles, int splits, int depth, int grid,
                           void* sink, void* stream);
+#endif
 
 /* Embedding lookup + the first RMSNorm of a forward in one pass (Engine/Llama_model.py:151 + the first layer's
  * input_layernorm, Engine/Llama_modules.py:282-288): x_out[r] = embed[ids[r]] (the residual stream, row-major),
@@ -402,7 +412,18 @@ int sq_ar_free(void* ptr);
 int sq_ar_ipc_export(void* ptr, void* handle64);
 int sq_ar_ipc_open(const void* handle64, void** ptr);
 int sq_ar_ipc_close(void* ptr);
-int sq_ar_status(const void* own_ws, int* status);      /* 0 ok; bit 0 / 1: a phase-1 / phase-2 flag never arrived (host sync) */
+int sq_ar_status(const void* own_ws, int* status);      /* 0 ok; bit 0 / 1: a phase-1 / phase-2 flag never arrived; bit 2 / 3: the
+                                                           all-gather's "written" / "read" flag (host sync)                  */
+/* Timeouts must not pass silently (a collective that gave up continues on stale areas): host_word = the device-visible
+ * address of a uint32 in pinned host memory; every timeout ORs its status bits into it as well, so the host loop can test
+ * it at every step without a device read (Tree/_native_tree.py raises on it).  NULL clears the registration.             */
+int sq_ar_set_fault_word(void* own_ws, void* host_word);
+/* Test rig (SEQUOIA_AR_WS=host): the workspace as a POSIX shared-memory object in fine-grained host memory, mapped by
+ * every rank and registered with the HIP runtime -- every store, flag and poll of the protocol then leaves the device
+ * (PCIe), which two ranks sharing ONE GPU's memory never do.  create != 0: create + zero `name`; returns the host mapping
+ * and the device-visible pointer to pass in ws[].  Close: unregister + unmap (+ unlink when name_to_unlink != NULL).     */
+int sq_ar_shared_host_open(const char* name, size_t bytes, int create, void** host_ptr, void** dev_ptr);
+int sq_ar_shared_host_close(const char* name_to_unlink, void* host_ptr, size_t bytes);
 int sq_allreduce_sum_f16(void* data, size_t n, int rank, int world, void* const* ws, size_t max_elems, int blocks,
                          void* stream);
 /* The same all-reduce fed by a split-K row-parallel projection: slab = fp32 [splits][n] partial products of this rank
@@ -428,6 +449,8 @@ int sq_allreduce_add_rmsnorm_f16(const void* slab, int splits, const void* in_ro
                                  size_t max_elems, void* stream);
 
 /* ---- f1: RMSNorm folded into the projection that consumes it (small draft models) ------------------------------
+ * EXPERIMENTAL: measured 8 % slower than the unfused launch sequence on MI355X (profiles/r03_draft_fused_not_adopted.md);
+ * opt-in (SEQUOIA_DRAFT_FUSED=1), kept for the measurement and its tests; the signature may change or disappear.
  * out = epilogue( (RMSNorm(x) * norm_weight) . w^T ) for m <= 48 rows and k in {256, 512, 768, 1024} (the 68m / 160m drafts): every
  * workgroup normalises the whole activation block itself into LDS, so the separate norm launch in front of
  * q/k/v_proj, gate/up_proj and lm_head (Engine/Llama_modules.py:282-288,341-346; Engine/Llama_model.py:280-283)

@@ -303,6 +303,8 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
             def spy(**kw):
                 out = orig_inf(**kw)
                 raw_box["logits"] = out
+                if top_p < 1.0:          # get_sampling_logits filters these rows IN PLACE (utils.py:76): keep the raw ones too
+                    raw_box["logits_raw"] = out.clone()
                 return out
             target.inference = spy
             kvc = target.engine.kv_cache
@@ -325,6 +327,10 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
                 arrays[f"{pre}/path_nodes"] = np.array(path_nodes, dtype=np.int64)
                 arrays[f"{pre}/path_target_rows"] = tl_n[path_nodes]
                 arrays[f"{pre}/path_draft_rows"] = dl_pre[path_nodes]
+                if top_p < 1.0:          # path_target_rows are the FILTERED rows (removed tokens at -inf); these the raw ones
+                    tr = raw_box["logits_raw"][0]
+                    tr_n = tr[-n:].numpy() if tr.shape[0] >= n else tr.numpy()
+                    arrays[f"{pre}/path_target_rows_raw"] = tr_n[path_nodes].copy()
             if compact and mode == "greedy":
                 # decision margins of the step (full rows are not stored): per internal node the k + 1 largest draft logits
                 # (k = its number of children: the top-k cut and the order inside it) and per node the gap between the two
@@ -566,16 +572,28 @@ def main():
     run_case(R, "V32k_seq128", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), d68, t160, 32000,
              384, 0.6, "stochastic", 32, 5, 25, logit_gain=10.0, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.005,
              out_dir=out_dir)
+    # the same pair and growmap under the reference harness's DEFAULT nucleus filter: tests/testbed.py:28 defaults to --P 0.9
+    # (every shipped script passes --P 1.0); SpecTree.verify filters the target rows with get_sampling_logits (utils.py:65-77,
+    # Tree/SpecTree.py:196) before the softmax
+    run_case(R, "B_topp09", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), d68, t160, 32000,
+             384, 0.6, "stochastic", 32, 5, 26, logit_gain=10.0, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.005,
+             top_p=0.9, out_dir=out_dir)
     # the headline dims (BASELINE.json configs[1] / [2]): 68m-dims draft -> Llama-2-7b-dims target (32 layers, 32 heads of
     # D = 128, hidden 4096, inter 11008), V = 32000, M = 384, 128-token prompt like tests/testbed.py:57.  Weights seeded
     # (13.5 GB of fp16 regenerated bit for bit on the GPU box); the target's leading 768 hidden dimensions carry most of
     # the embedding / lm_head energy so that the 768-wide draft built from those slices gets accepted to a useful degree.
     t7b = (4096, 11008, 32, 32, 32)
+    # Round 4: the knobs were re-tuned for DEEP accepted paths (round 3's pair accepted 1, 1, 1, 0 tree tokens per step on
+    # C_7b: depth >= 3, the -65504 rebase and the commit-order quirk were only exercised at hidden <= 768): the lead
+    # dimensions carry 8x (not 3x) the embedding / lm_head scale, the draft is the target's leading slice + 2 % noise, and the
+    # draft's lm_head is scaled by 2.23 -- the ratio of the two models' RMSNorm scales on the lead dimensions -- so that draft
+    # and target sit at the same temperature.  The decoder branches keep round 3's scale (0.0015: 32 layers of branches add
+    # up to about the embedding's magnitude -- the layers matter to the logits).
+    knobs7b = dict(logit_gain=1.0, seeded=True, share_vocab=0.02, compact=16, branch_scale=0.0015, lead=(768, 8.0),
+                   draft_lm_scale=2.23)
     run_case(R, "B_7b", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), d68, t7b, 32000, 384, 0.6,
-             "stochastic", 128, 4, 41, logit_gain=3.0, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.0015,
-             lead=(768, 3.0), out_dir=out_dir)
-    run_case(R, "C_7b", gm("L40_growmaps/8x8-tree.pt"), d68, t7b, 32000, 384, 0.6, "greedy", 128, 4, 41, logit_gain=3.0,
-             seeded=True, share_vocab=0.05, compact=16, branch_scale=0.0015, lead=(768, 3.0), out_dir=out_dir)
+             "stochastic", 128, 4, 41, out_dir=out_dir, **knobs7b)
+    run_case(R, "C_7b", gm("L40_growmaps/8x8-tree.pt"), d68, t7b, 32000, 384, 0.6, "greedy", 128, 4, 41, out_dir=out_dir, **knobs7b)
     # configuration D at its real WIDTHS (BASELINE.json configs[3]): Sheared-LLaMA-1.3B dims draft (hidden 2048, 16 heads of 128,
     # inter 5504) -> Llama-2-13b dims target (hidden 5120, 40 heads of 128, inter 13824), 4 layers each (the widths decide
     # the kernels' shapes and launch plans -- the 13B plans mix the tall-skinny kernel with hipBLASLt -- the depth only

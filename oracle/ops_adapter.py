@@ -40,6 +40,10 @@ class OracleOps:
         sl = [int(s) for s in _np(slots)[:c]] if c > 0 else []
         O.kv_compact(_np(k_cache)[:, 0], _np(v_cache)[:, 0], sl, dst_offset, zero_end)
 
+    def kv_compact2(self, kv0, kv1, slots, count, max_count, dst_offset, dst_offset_dev=None):
+        for kv in (kv0, kv1):
+            self.kv_compact(kv.k_cache, kv.v_cache, slots, count, max_count, dst_offset, 0, dst_offset_dev=dst_offset_dev)
+
     def kv_clear(self, k_cache, v_cache, used_rows):
         O.kv_clear(_np(k_cache)[:, 0], _np(v_cache)[:, 0], used_rows)
 

@@ -58,6 +58,10 @@ def plan_key(n_out: int, k: int, silu: bool, mtp: int) -> str:
 SPLITTABLE = ("qkv", "o", "down", "gate_up")   # projections whose consumer reads split-K slabs: RoPE + KV write (qkv), the
 #   residual add + RMSNorm (o, down), the SwiGLU pass (gate_up: run as a plain [2 inter] x k layer, sq_silu_mul_slabs_f16)
 MAX_SPLITS = 8
+# K-splits a launch plan may ask for, per projection: the SwiGLU layer's split candidates stop at 4 (`candidates`), so its
+# [2 inter]-wide partials never need more than 4 slabs -- the persistent slab buffer is sized by what can be used, not by
+# MAX_SPLITS x the widest projection (70B widths: 132 MB instead of 264 MB per model)
+SPLITS_CAP = {"qkv": MAX_SPLITS, "o": MAX_SPLITS, "down": MAX_SPLITS, "gate_up": 4}
 
 
 def candidates(n_out: int, k: int, silu: bool, m: int, allow_split: bool = False):
@@ -111,7 +115,7 @@ class TsLinearSet:
         self.exclusive = False
         self._zero_rows = torch.zeros((MAX_ROWS, d.hidden_size), dtype=torch.float16, device=self.device)
         # split-K partials [splits][rows][n_out] fp32: one buffer for the model's life (captured graphs hold it)
-        self._slab = torch.empty(MAX_SPLITS * MAX_ROWS * max(self.shapes[n][0] * (2 if self.shapes[n][2] else 1) for n in SPLITTABLE),
+        self._slab = torch.empty(MAX_ROWS * max(SPLITS_CAP[n] * self.shapes[n][0] * (2 if self.shapes[n][2] else 1) for n in SPLITTABLE),
                                  dtype=torch.float32, device=self.device)
 
     @staticmethod
@@ -216,6 +220,9 @@ class TsLinearSet:
                     rec = "torch" if name == "lm_head" else self.default_plan(name, q_len)
                 elif rec is None:
                     rec = self.autotune(name, q_len)
+                if rec != "torch" and int(rec[1]) > SPLITS_CAP.get(name, 1):
+                    raise ValueError(f"launch plan {plan_key(n_out, k, silu, mtp)} = {rec}: {name} takes at most "
+                                     f"{SPLITS_CAP.get(name, 1)} K-splits (the split-K slab buffer is sized for that)")
                 p[name] = None if rec == "torch" else (int(rec[0]), int(rec[1]))
             if not capturing:
                 for name, v in p.items():                   # materialise the weight images now, outside any capture

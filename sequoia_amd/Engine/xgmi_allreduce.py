@@ -21,14 +21,62 @@ import torch.distributed as dist
 from .. import native
 
 
+# Where the workspaces live: "device" (default) = uncached device memory exported through hipIpc -- across GPUs the peers'
+# stores travel over xGMI; "host" = a test rig: POSIX shared memory registered with the HIP runtime, so that on a ONE-GPU box
+# every store, flag and poll of the protocol really leaves the device (PCIe) instead of meeting in the same HBM / L2 fabric
+# (VERDICT r03 #4a: a missing system-scope fence or a cached flag read cannot hide there).
+WS_MODE = os.environ.get("SEQUOIA_AR_WS", "device")
+LAST_REFUSAL = None          # why the last create() handed back None (bench.py prints it)
+_LIVE = []                   # weak references to every live instance (raise_on_fault)
+
+FAULT_BITS = {1: "all-reduce phase 1 (a peer's partial rows never arrived)", 2: "all-reduce phase 2 (a peer's reduced chunk never arrived)",
+              4: "all-gather 'written' flag", 8: "all-gather 'read' flag of the previous gather"}
+
+
+class XgmiCollectiveTimeout(RuntimeError):
+    pass
+
+
+def raise_on_fault():
+    """Called by the speculation loop once per step (Tree/_native_tree.py::verify / collect_step): a collective kernel whose
+    bounded spin ran out has continued on stale data -- every token decided after that is wrong, so the job stops here.
+    Costs a read of one word of pinned host memory per live instance; nothing when no instance exists."""
+    for ref in _LIVE:
+        ar = ref()
+        if ar is not None:
+            ar.check_fault()
+
+
 class XgmiAllReduce:
-    def __init__(self, lib, rank, world, ws_ptrs, own, opened, max_elems, device, group, max_gather_elems=0):
+    def __init__(self, lib, rank, world, ws_ptrs, own, opened, max_elems, device, group, max_gather_elems=0, shared=None):
         self.lib, self.rank, self.world = lib, rank, world
         self._own, self._opened = own, opened
+        self._shared = shared          # host mode: {"name", "host", "bytes", "peers": [(host_ptr, bytes)]}
         self.max_elems, self.max_gather_elems = max_elems, max_gather_elems
         self.device, self.group = device, group
         self._table = (C.c_void_p * world)(*ws_ptrs)
         self.calls = 0
+        # the fault word: pinned host memory the kernels OR their timeout bits into (sq_ar_set_fault_word)
+        self.fault = torch.zeros(16, dtype=torch.int32).pin_memory()
+        own_ptr = own if isinstance(own, C.c_void_p) else C.c_void_p(own)
+        if lib.sq_ar_set_fault_word(own_ptr, C.c_void_p(self.fault.data_ptr())) != native.SQ_OK:
+            self.fault = None
+        import weakref
+        _LIVE.append(weakref.ref(self))
+
+    def check_fault(self):
+        if self.fault is None:
+            return
+        bits = int(self.fault[0])
+        if bits:
+            what = "; ".join(v for k, v in FAULT_BITS.items() if bits & k)
+            raise XgmiCollectiveTimeout(f"rank {self.rank}: an xGMI collective gave up waiting for a peer (status bits {bits}: {what}); "
+                                        "its result is invalid -- everything decoded after it would be too")
+
+    def clear_fault(self):
+        """Tests that provoke a timeout on purpose."""
+        if self.fault is not None:
+            self.fault.zero_()
 
     # ---- setup ------------------------------------------------------------------------------------------------
     @staticmethod
@@ -43,6 +91,8 @@ class XgmiAllReduce:
         lib = native.load()
         torch.cuda.set_device(device)
         nbytes = int(lib.sq_ar_workspace_bytes(world, max_elems, max_gather_elems))
+        if WS_MODE == "host":
+            return XgmiAllReduce._create_host(lib, group, device, world, rank, nbytes, max_elems, max_gather_elems, self_check)
         own = C.c_void_p()
         ok = lib.sq_ar_alloc(C.byref(own), nbytes) == native.SQ_OK
         handle = (C.c_ubyte * 64)()
@@ -76,6 +126,46 @@ class XgmiAllReduce:
         if any(flags):
             ar.close()
             return _refuse(rank, "hipIpcOpenMemHandle failed on rank(s) " + str([r for r, f in enumerate(flags) if f]))
+        if self_check and not ar._self_check():
+            ar.close()
+            return None
+        return ar
+
+    @staticmethod
+    def _create_host(lib, group, device, world, rank, nbytes, max_elems, max_gather_elems, self_check):
+        """SEQUOIA_AR_WS=host: every rank creates one shared-memory object, the NAMES are exchanged, every rank maps and
+        registers every peer's object (sq_ar_shared_host_open)."""
+        global _SHM_SEQ
+        _SHM_SEQ += 1
+        name = f"/sequoia_ar_{os.getpid()}_{rank}_{_SHM_SEQ}".encode()
+        host, devp = C.c_void_p(), C.c_void_p()
+        ok = lib.sq_ar_shared_host_open(name, nbytes, 1, C.byref(host), C.byref(devp)) == native.SQ_OK
+        infos = [None] * world
+        dist.all_gather_object(infos, (bool(ok), name), group=group)
+        if not all(i[0] for i in infos):
+            if ok:
+                lib.sq_ar_shared_host_close(name, host, nbytes)
+            return _refuse(rank, "host-memory workspace (shm_open / hipHostRegister) failed on rank(s) "
+                           + str([r for r, i in enumerate(infos) if not i[0]]))
+        ptrs, peers, failed = [], [], False
+        for r, (_, pname) in enumerate(infos):
+            if r == rank:
+                ptrs.append(devp.value)
+                continue
+            ph, pd = C.c_void_p(), C.c_void_p()
+            if lib.sq_ar_shared_host_open(pname, nbytes, 0, C.byref(ph), C.byref(pd)) != native.SQ_OK:
+                failed = True
+                ptrs.append(devp.value)
+            else:
+                ptrs.append(pd.value)
+                peers.append((ph.value, nbytes))
+        flags = [None] * world
+        dist.all_gather_object(flags, failed, group=group)      # (also: every rank has mapped every object -> names may go)
+        shared = dict(name=name, host=host.value, bytes=nbytes, peers=peers)
+        ar = XgmiAllReduce(lib, rank, world, ptrs, devp, [], max_elems, device, group, max_gather_elems, shared=shared)
+        if any(flags):
+            ar.close()
+            return _refuse(rank, "mapping a peer's host-memory workspace failed on rank(s) " + str([r for r, f in enumerate(flags) if f]))
         if self_check and not ar._self_check():
             ar.close()
             return None
@@ -140,6 +230,7 @@ class XgmiAllReduce:
         if not all(verdicts):
             _refuse(self.rank, f"self-check against dist.all_reduce failed on rank(s) {[r for r, v in enumerate(verdicts) if not v]}"
                                f" (status {self.status()})")
+        self.clear_fault()       # (a failed self-check may have raised bits: the instance is closed by the caller anyway)
         return all(verdicts)
 
     # ---- the call ---------------------------------------------------------------------------------------------
@@ -212,6 +303,14 @@ class XgmiAllReduce:
         return int(st.value)
 
     def close(self):
+        if self._shared is not None:
+            sh, self._shared = self._shared, None
+            torch.cuda.synchronize(self.device)
+            for ph, nb in sh["peers"]:
+                self.lib.sq_ar_shared_host_close(None, C.c_void_p(ph), nb)
+            self.lib.sq_ar_shared_host_close(sh["name"], C.c_void_p(sh["host"]), sh["bytes"])
+            self._own = None
+            return
         for p in self._opened:
             self.lib.sq_ar_ipc_close(C.c_void_p(p))
         self._opened = []
@@ -220,7 +319,12 @@ class XgmiAllReduce:
             self._own = None
 
 
+_SHM_SEQ = 0
+
+
 def _refuse(rank, why):
+    global LAST_REFUSAL
+    LAST_REFUSAL = why
     if rank == 0:
         import sys
         print(f"sequoia_amd: xGMI all-reduce disabled ({why}); staying on RCCL", file=sys.stderr)

@@ -17,10 +17,13 @@ import time
 import torch
 
 from ..Engine.Llama_modules import TreeContext
-from ..native import (SQ_REASON_SKIPPED, SQ_VERIFY_GATHER_FIRST, SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_TERMINAL,
+from ..native import (SQ_REASON_SKIPPED, SQ_VERIFY_GATHER_FIRST, SQ_RES_ACCEPT_LEN, SQ_RES_N_TREE, SQ_RES_SLOTS, SQ_RES_TERMINAL,
                       SQ_RESULT_INTS, SQ_RESULT_RING)
 from ..ops import get_ops
 from .Tree import Tree, growmap_on_device
+
+
+from ..Engine import xgmi_allreduce as _xgmi       # noqa: E402  (the per-step fault check of tensor-parallel jobs)
 
 
 def _sync(device):
@@ -36,7 +39,13 @@ def _sync(device):
 # store the bonus token, so the committed text is exactly the accepted path (the algorithm as published):
 # SEQUOIA_COMMIT_ORDER=lossless, or `commit_order="lossless"` per tree.  bench.py prints the order it ran with
 # (`config.commit_order`) and times its CPU baseline with the same one.
+# The quirk is OBSERVABLE, not silent: every step that commits a bonus id over an accepted token is counted
+# (QUIRK_STEPS, tree.quirk_steps; bench.py prints the count) and the first one of a process raises a warning that names the
+# switch.  The KV rows are deliberately left alone: they are the accepted token's -- the context every later step
+# conditions on is the accepted path, only the reported id at that one position is off; rewriting the rows to match the
+# id would make the model state follow the glitch instead.
 COMMIT_ORDER = os.environ.get("SEQUOIA_COMMIT_ORDER", "reference")
+QUIRK_STEPS = [0]
 if COMMIT_ORDER not in ("reference", "lossless"):
     raise ValueError(f"SEQUOIA_COMMIT_ORDER must be 'reference' or 'lossless', got {COMMIT_ORDER!r}")
 # Device-driven step (Tree/step_graph.py): "1" = every tree adopts the static step buffers and can run pipelined steps
@@ -233,11 +242,14 @@ class NativeTree(Tree):
 
         self._verify_native(gt)
         res = self.result.cpu()                      # the step's only device->host synchronisation
+        if _xgmi._LIVE:
+            _xgmi.raise_on_fault()                   # a collective that timed out: stop here, do not decode on stale sums
         accept_length = int(res[SQ_RES_ACCEPT_LEN])
         n_acc = int(res[SQ_RES_N_TREE])
         terminal = bool(res[SQ_RES_TERMINAL])
         self.last_result = res
         accept_list = self.seq_to_use[:gt] + [int(s) for s in res[SQ_RESULT_INTS:SQ_RESULT_INTS + n_acc]]
+        self._note_commit_quirk(accept_length, accept_list[gt:], terminal)
         if benchmark:
             _sync(self.device); t3 = time.time()
         self.step_idx += 1
@@ -287,6 +299,22 @@ class NativeTree(Tree):
         self.draft_logits[0] = logits[0, -1]
         self.draft_kv_len = new_gt
         self.target_kv_len = a
+
+    quirk_steps = 0
+
+    def _note_commit_quirk(self, a: int, slots, terminal: bool):
+        """commit_order == "reference": the bonus token was stored at slot a BEFORE tokens[gt:a] = tokens[accepted slots]
+        (Tree/SpecTree.py:222-224); when an accepted node sits at slot a its committed id is the bonus token's."""
+        if terminal or not self.stochastic or self.commit_order != "reference" or a not in slots:
+            return
+        self.quirk_steps += 1
+        QUIRK_STEPS[0] += 1
+        if QUIRK_STEPS[0] == 1:
+            import warnings
+            warnings.warn("sequoia_amd: this step committed the bonus token's id over an accepted token (the reference's "
+                          "store-before-gather order, Tree/SpecTree.py:222-224, reproduced for token parity; the KV cache holds "
+                          "the accepted token).  SEQUOIA_COMMIT_ORDER=lossless / commit_order='lossless' commits the accepted "
+                          "path itself.  Further occurrences are counted in sequoia_amd.Tree._native_tree.QUIRK_STEPS.", stacklevel=3)
 
     _compact_when_terminal = True
     _prepare_next = True       # the acceptance probes rebuild the tree every step: no next-root forward (Tree/SpecTree.py:283)
@@ -344,6 +372,8 @@ class NativeTree(Tree):
                 if (spins & 0xfff) == 0 and time.time() - t0 > timeout_s:
                     raise RuntimeError(f"step {idx}: no result record after {timeout_s} s")
         rec = rec.copy()
+        if _xgmi._LIVE:
+            _xgmi.raise_on_fault()                   # (the fault word is pinned host memory: no device read)
         a, n_acc, bonus, terminal = int(rec[SQ_RES_ACCEPT_LEN]), int(rec[SQ_RES_N_TREE]), int(rec[2]), bool(rec[SQ_RES_TERMINAL])
         assert int(rec[7]) == idx, f"result ring slot {idx % SQ_RESULT_RING} holds step {int(rec[7])}, expected {idx}"
         if p["dead"]:
@@ -353,6 +383,7 @@ class NativeTree(Tree):
             return self.ground_truth_len, 0, -1, True
         self.last_result = rec
         self.step_idx = idx + 1
+        self._note_commit_quirk(a, [int(x) for x in rec[SQ_RES_SLOTS:SQ_RES_SLOTS + min(n_acc, SQ_RESULT_INTS - SQ_RES_SLOTS)]], terminal)
         if terminal:
             p["dead"] = True
         else:

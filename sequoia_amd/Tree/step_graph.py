@@ -129,9 +129,8 @@ class StepState:
             ops.verify_greedy(target_logits, self.tokens, g["child_off"], g["child_ids"], n, 0, self.verify_ws, self.result,
                               step=self.step, result_ring=self.ring)
         slots, count = self.result[SQ_RESULT_INTS:], self.result[SQ_RES_N_TREE:SQ_RES_N_TREE + 1]
-        for eng in (dm, tm):
-            kv = eng.kv_cache
-            ops.kv_compact(kv.k_cache, kv.v_cache, slots, count, g["max_depth"], 0, 0, dst_offset_dev=gt_dev)
+        # both caches roll back to the accepted path in one launch (Tree/SpecTree.py:226-227)
+        ops.kv_compact2(dm.kv_cache, tm.kv_cache, slots, count, g["max_depth"], 0, dst_offset_dev=gt_dev)
         f = self.fwd_one                                   # next root: the bonus token at slot new_gt - 1
         self._stage(f, -1, 0, advance=True)
         logits = dm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None, tree=f.tree)

@@ -26,7 +26,8 @@
 #define AR_FLAG_STRIDE 16                 // uint32 per flag slot: one 64-byte line each
 #define AR_SPIN_LIMIT (1u << 22)          // x (poll + s_sleep) ~ a few seconds; SEQUOIA_AR_SPIN_LIMIT overrides (tests)
 
-// workspace layout (bytes): [header 4 KB: status, per-block epochs] [flags1][flags2][area A: W slots][area B: n elements]
+// workspace layout (bytes): [header 4 KB: +0 status bits, +8 address of the external fault word, +256 / +512 per-block epochs]
+// [flags1][flags2][area A: W slots][area B: n elements]
 // [area C: the all-gather's [rows][W v] image]
 struct ArLayout {
     size_t flags1, flags2, area_a, area_b, area_c, total, chunk_cap;
@@ -55,6 +56,17 @@ struct ArParams {
     int rank, world, blocks;
     uint32_t spin_limit;
 };
+
+// A bounded spin that ran out: the collective continues on whatever its areas hold, so the result is WRONG from here on.
+// The bit goes into the workspace's status word and -- when the owner registered one (sq_ar_set_fault_word) -- into a
+// word in pinned host memory that the host loop reads for free at every step (Tree/_native_tree.py::collect_step /
+// verify raise on it): a tensor-parallel job fails loudly at the step after the timeout instead of decoding on stale
+// partial sums (the status word used to be read by the self-check and bench.py only).
+__device__ __forceinline__ void ar_fault(char* mine, uint32_t bits) {
+    atomicOr((uint32_t*)mine, bits);
+    uint32_t* ext = *(uint32_t* const*)(mine + 8);
+    if (ext) __hip_atomic_fetch_or(ext, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ void ar_flag_store(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -91,7 +103,6 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const Ar
     const int b = blockIdx.x, tid = threadIdx.x, W = P.world, R = P.rank;
     const ArLayout L = ar_layout(W, P.max_elems);
     char* mine = P.ws[R];
-    uint32_t* status = (uint32_t*)mine;                       // [0] error bits
     uint32_t* epochs = (uint32_t*)(mine + 256);               // [blocks]
     __shared__ uint32_t s_epoch;
     if (tid == 0) s_epoch = epochs[b] + 1;
@@ -120,7 +131,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const Ar
     // ---- phase 2: reduce my chunk (rank order, fp32), publish it to every peer's area B ----------------------------------
     if (tid < W && tid != R) {
         if (!ar_flag_wait((const uint32_t*)(mine + L.flags1) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit)) {
-            atomicOr(status, 1u);
+            ar_fault(mine, 1u);
         }
     }
     __syncthreads();
@@ -156,7 +167,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const Ar
     // ---- phase 3: the other ranks' reduced chunks -> the caller's tensor ----------------------------------------------------
     if (tid < W && tid != R) {
         if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit)) {
-            atomicOr(status, 2u);
+            ar_fault(mine, 2u);
         }
     }
     __syncthreads();
@@ -186,6 +197,53 @@ extern "C" int sq_ar_alloc(void** ptr, size_t bytes) {
     if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return SQ_ELAUNCH; }
     *ptr = p;
     return SQ_OK;
+}
+
+// Fault word: a uint32 in pinned (fine-grained, device-visible) host memory that every timeout ORs its bit into.
+// host_word = the DEVICE-visible address of that word (0 clears it).  Stored in the workspace header at byte 8.
+extern "C" int sq_ar_set_fault_word(void* own_ws, void* host_word) {
+    if (!own_ws) return SQ_EINVAL;
+    const uint64_t v = (uint64_t)(uintptr_t)host_word;
+    if (hipMemcpy((char*)own_ws + 8, &v, sizeof(v), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return SQ_ELAUNCH; }
+    return SQ_OK;
+}
+
+// Workspaces in fine-grained HOST memory shared between processes (SEQUOIA_AR_WS=host; a test rig, not a fast path): a POSIX
+// shared-memory object mapped by every rank and registered with the HIP runtime (hipHostRegisterMapped), so that every
+// payload store, flag store and flag poll of the protocol leaves the device over PCIe -- no XCD L2 and no local HBM can
+// make a missing system-scope fence or a cached flag read look correct the way two ranks on ONE GPU's memory can.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+extern "C" int sq_ar_shared_host_open(const char* name, size_t bytes, int create, void** host_ptr, void** dev_ptr) {
+    if (!name || !host_ptr || !dev_ptr || bytes == 0) return SQ_EINVAL;
+    const int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) return SQ_EUNSUPPORTED;
+    if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); return SQ_EUNSUPPORTED; }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { if (create) shm_unlink(name); return SQ_EUNSUPPORTED; }
+    if (create) memset(p, 0, bytes);
+    void* d = nullptr;
+    if (hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess ||
+        hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d) {
+        (void)hipGetLastError();
+        munmap(p, bytes);
+        if (create) shm_unlink(name);
+        return SQ_EUNSUPPORTED;
+    }
+    *host_ptr = p; *dev_ptr = d;
+    return SQ_OK;
+}
+
+extern "C" int sq_ar_shared_host_close(const char* name_to_unlink, void* host_ptr, size_t bytes) {
+    int rc = SQ_OK;
+    if (host_ptr) {
+        if (hipHostUnregister(host_ptr) != hipSuccess) { (void)hipGetLastError(); rc = SQ_EINVAL; }
+        munmap(host_ptr, bytes);
+    }
+    if (name_to_unlink) shm_unlink(name_to_unlink);
+    return rc;
 }
 
 extern "C" int sq_ar_free(void* ptr) {
@@ -278,23 +336,25 @@ __global__ void __launch_bounds__(AR_THREADS) allgather_cols_kernel(const AgPara
     const int b = blockIdx.x, tid = threadIdx.x, W = P.world, R = P.rank;
     const ArLayout L = ar_layout(W, P.max_elems, P.gather_elems);
     char* mine = P.ws[R];
-    uint32_t* status = (uint32_t*)mine;
     uint32_t* epochs = (uint32_t*)(mine + 512);               // [blocks] (the all-reduce keeps its own at + 256)
     __shared__ uint32_t s_epoch;
     if (tid == 0) s_epoch = epochs[b] + 1;
     __syncthreads();
     const uint32_t epoch = s_epoch;
-    const int r0 = (int)((long)P.rows * b / P.blocks), r1 = (int)((long)P.rows * (b + 1) / P.blocks);
+    // rows are dealt to blocks by a map that does not depend on the row count of the call: row i belongs to block i % 64
+    // (blocks = min(rows, 64): stride `blocks` from b).  The "read" handshake below is per (peer, block); with a map that
+    // moved with `rows`, two gathers of different heights could have a block overwrite rows of a peer's image that ANOTHER
+    // block of that peer was still reading from the previous gather.
     const int vec = P.v / 8;                                  // 16-byte vectors per slice row
     const size_t ld = (size_t)W * P.v;
     // the peers have read the previous image out of their area C (word + 12 of the flag line = "read" epoch)
     if (tid < W && tid != R) {
         if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 12, epoch - 1, P.spin_limit))
-            atomicOr(status, 8u);
+            ar_fault(mine, 8u);
     }
     __syncthreads();
     // my slice -> my own output and every peer's area C (final layout)
-    for (int i = r0; i < r1; ++i) {
+    for (int i = b; i < P.rows; i += P.blocks) {
         for (int c = tid; c < vec; c += AR_THREADS) {
             const half8 x = *(const half8*)(P.slice + (size_t)i * P.v + c * 8);
             const size_t off = (size_t)i * ld + (size_t)R * P.v + c * 8;
@@ -311,11 +371,11 @@ __global__ void __launch_bounds__(AR_THREADS) allgather_cols_kernel(const AgPara
         ar_flag_store((uint32_t*)(P.ws[tid] + L.flags2) + ((size_t)R * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 8, epoch);
     if (tid < W && tid != R) {
         if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 8, epoch, P.spin_limit))
-            atomicOr(status, 4u);
+            ar_fault(mine, 4u);
     }
     __syncthreads();
     const half_t* img = (const half_t*)(mine + L.area_c);
-    for (int i = r0; i < r1; ++i) {
+    for (int i = b; i < P.rows; i += P.blocks) {
         for (int d = 1; d < W; ++d) {
             const int p = (R + d) % W;
             for (int c = tid; c < vec; c += AR_THREADS) {
@@ -403,7 +463,6 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_add_rmsnorm_kernel(const
     const int b = blockIdx.x, tid = threadIdx.x, W = P.world, R = P.rank;
     const ArLayout L = ar_layout(W, P.max_elems);
     char* mine = P.ws[R];
-    uint32_t* status = (uint32_t*)mine;
     uint32_t* epochs = (uint32_t*)(mine + 256);
     __shared__ uint32_t s_epoch;
     if (tid == 0) s_epoch = epochs[b] + 1;
@@ -430,7 +489,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_add_rmsnorm_kernel(const
     // ---- phase 2: reduce my rows (rank order, fp32, one rounding), publish them to every rank's area B (mine included) -----
     if (tid < W && tid != R) {
         if (!ar_flag_wait((const uint32_t*)(mine + L.flags1) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit))
-            atomicOr(status, 1u);
+            ar_fault(mine, 1u);
     }
     __syncthreads();
     {
@@ -464,7 +523,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_add_rmsnorm_kernel(const
     // ---- phase 3: every chunk's rows of this block are complete here: residual add + RMSNorm --------------------------------
     if (tid < W && tid != R) {
         if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit))
-            atomicOr(status, 2u);
+            ar_fault(mine, 2u);
     }
     __syncthreads();
     const half_t* bsrc = (const half_t*)(mine + L.area_b);

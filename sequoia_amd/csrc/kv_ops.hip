@@ -171,10 +171,8 @@ extern "C" int sq_kv_scatter_f16(void* k_layer, void* v_layer, const void* new_k
 // store of that pass, and passes run in ascending order, which is safe because the slots are
 // ascending and dst_j <= slot_j (BFS slot order), so a store can only overwrite a source that was
 // already consumed (SURVEY.md §7 "KV compaction aliasing").
-__global__ void __launch_bounds__(256) kv_compact_kernel(half_t* k_cache, half_t* v_cache, int m, int d,
-                                                         const int32_t* slots, const int32_t* d_count, int max_count,
-                                                         int dst_offset, int zero_end, const int32_t* d_dst_offset) {
-    half_t* tile = (blockIdx.y == 0 ? k_cache : v_cache) + (size_t)blockIdx.x * m * d;
+__device__ __forceinline__ void kv_compact_tile(half_t* tile, int m, int d, const int32_t* slots, const int32_t* d_count,
+                                                int max_count, int dst_offset, int zero_end, const int32_t* d_dst_offset) {
     if (d_dst_offset) dst_offset = *d_dst_offset;          // device-driven step: the ground-truth length lives on the device
     int count = d_count ? *d_count : max_count;
     if (count > max_count) count = max_count;
@@ -203,6 +201,41 @@ __global__ void __launch_bounds__(256) kv_compact_kernel(half_t* k_cache, half_t
         u32x4* p = (u32x4*)(tile + (size_t)z0 * d);
         for (int c = threadIdx.x; c < n_chunks; c += 256) p[c] = zero;
     }
+}
+
+__global__ void __launch_bounds__(256) kv_compact_kernel(half_t* k_cache, half_t* v_cache, int m, int d,
+                                                         const int32_t* slots, const int32_t* d_count, int max_count,
+                                                         int dst_offset, int zero_end, const int32_t* d_dst_offset) {
+    half_t* tile = (blockIdx.y == 0 ? k_cache : v_cache) + (size_t)blockIdx.x * m * d;
+    kv_compact_tile(tile, m, d, slots, d_count, max_count, dst_offset, zero_end, d_dst_offset);
+}
+
+// Both caches of a speculation step (draft + target: the same accepted slots, the same destination) in ONE launch: the
+// device-driven step rolls the draft cache and the target cache back to the accepted path back to back
+// (Tree/SpecTree.py:226-227); as two dependent graph nodes the second costs a kernel boundary for ~1 us of work.
+struct KvPair { half_t *k0, *v0, *k1, *v1; int tiles0, m0, d0, tiles1, m1, d1; };
+__global__ void __launch_bounds__(256) kv_compact2_kernel(const KvPair P, const int32_t* slots, const int32_t* d_count, int max_count,
+                                                          int dst_offset, const int32_t* d_dst_offset) {
+    const int b = blockIdx.x;
+    const bool second = b >= P.tiles0;
+    const int t = second ? b - P.tiles0 : b, m = second ? P.m1 : P.m0, d = second ? P.d1 : P.d0;
+    half_t* base = blockIdx.y == 0 ? (second ? P.k1 : P.k0) : (second ? P.v1 : P.v0);
+    kv_compact_tile(base + (size_t)t * m * d, m, d, slots, d_count, max_count, dst_offset, 0, d_dst_offset);
+}
+
+extern "C" int sq_kv_compact2_f16(void* k0, void* v0, int n_layers0, int h_kv0, int m0, int d0, void* k1, void* v1, int n_layers1,
+                                  int h_kv1, int m1, int d1, const int32_t* d_slots, const int32_t* d_count, int max_count,
+                                  int dst_offset, const int32_t* d_dst_offset, void* stream) {
+    if (!k0 || !v0 || !k1 || !v1 || n_layers0 <= 0 || h_kv0 <= 0 || m0 <= 0 || n_layers1 <= 0 || h_kv1 <= 0 || m1 <= 0 ||
+        max_count < 0 || dst_offset < 0) return SQ_EINVAL;
+    if (max_count > 0 && !d_slots) return SQ_EINVAL;
+    for (int d : {d0, d1})
+        if (d <= 0 || (d & 7) || d > 2048 || (256 % (d >> 3)) != 0) return SQ_EUNSUPPORTED;
+    if (max_count == 0 && !d_dst_offset) return SQ_OK;
+    KvPair P{(half_t*)k0, (half_t*)v0, (half_t*)k1, (half_t*)v1, n_layers0 * h_kv0, m0, d0, n_layers1 * h_kv1, m1, d1};
+    hipLaunchKernelGGL(kv_compact2_kernel, dim3(P.tiles0 + P.tiles1, 2), dim3(256), 0, (hipStream_t)stream, P, d_slots, d_count,
+                       max_count, dst_offset, d_dst_offset);
+    return sq_check_launch();
 }
 
 extern "C" int sq_kv_compact_f16(void* k_cache, void* v_cache, int n_layers, int h_kv, int m, int d,

@@ -40,6 +40,17 @@ extern "C" size_t sq_sample_workspace_bytes(int n_rows, int vocab, int k) {
     return samp_stats_bytes(n_rows, vocab) + (size_t)n_rows * samp_parts(vocab) * k * sizeof(unsigned long long) + 64;
 }
 
+// chunks past the row end: defined values (the element passes below are branch-free -- they evaluate the quotient / exp / log
+// of every register and select afterwards; indeterminate registers there would be undefined behaviour)
+__device__ __forceinline__ half8 samp_neg_inf8() {
+    const half_t n = (half_t)(-INFINITY);
+    return half8{n, n, n, n, n, n, n, n};
+}
+__device__ __forceinline__ half8 samp_half8(float v) {
+    const half_t n = (half_t)v;
+    return half8{n, n, n, n, n, n, n, n};
+}
+
 // ---- 1. per-part softmax statistics (+ optional row copy) ----------------------------------------------------------
 __global__ void __launch_bounds__(PART_THREADS)
 logits_stats_kernel(const half_t* __restrict__ logits, int64_t ld, const int32_t* __restrict__ row_ids, int vocab,
@@ -55,6 +66,7 @@ logits_stats_kernel(const half_t* __restrict__ logits, int64_t ld, const int32_t
 #pragma unroll
     for (int c = 0; c < PART_CH; ++c) {                     // every load of the thread in flight before the first use
         const int e0 = part_elem(p, c, t, 0);
+        xv[c] = samp_neg_inf8();
         if (e0 < vocab) xv[c] = *(const half8*)(x + e0);
     }
     if (copy_dst) {
@@ -181,6 +193,9 @@ sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const 
 #pragma unroll
         for (int c = 0; c < PART_CH; ++c) {
             const int e0 = part_elem(p, c, t, 0);
+            xv[c] = samp_neg_inf8();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) uv[c][j] = 0.5f;
             if (e0 < vocab) {
                 xv[c] = *(const half8*)(x + e0);
                 const floatx4 a = *(const floatx4*)(u + e0), b = *(const floatx4*)(u + e0 + 4);
@@ -211,6 +226,7 @@ sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const 
 #pragma unroll
         for (int c = 0; c < PART_CH; ++c) {
             const int e0 = part_elem(p, c, t, 0);
+            xv[c] = samp_neg_inf8(); uv[c] = samp_half8(0.5f);
             if (e0 < vocab) { xv[c] = *(const half8*)(x + e0); uv[c] = *(const half8*)(u + e0); }
         }
         float M, z;
@@ -237,6 +253,7 @@ sample_parts_kernel(const half_t* __restrict__ logits, int64_t ld_logits, const 
 #pragma unroll
         for (int c = 0; c < PART_CH; ++c) {                      // both loads in flight before the first use
             const int e0 = part_elem(p, c, t, 0);
+            xv[c] = samp_neg_inf8();
             if (e0 < vocab) xv[c] = *(const half8*)(x + e0);
         }
 #pragma unroll

@@ -108,6 +108,7 @@ class Loop:
         self.cfg, self.draft, self.target, self.device, self.prompts, self.T = cfg, draft, target, device, prompts, T
         self.top_p, self.max_new, self.vocab = top_p, max_new, vocab
         self.grow_map = gm.to_reference_dict()
+        self.gm_obj = gm
         self.cls = SpecTree if cfg["mode"] == "stochastic" else GreedyTree
         M = cfg["M"]
         self.attn_mask = torch.full((M, M), torch.finfo(torch.float16).min, dtype=torch.float16, device=device)

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "sq_tree_mask_dense_f16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "sq_kv_scatter_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sq_kv_compact_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sq_kv_compact2_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "sq_kv_clear_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_rope_kv_write_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_rope_kv_write_slabs_f16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -61,7 +62,6 @@ PROTOTYPES = {
     "sq_add_rmsnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_linear_ts_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "sq_linear_ts_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp]),
-    "sq_linear_ts_prefetch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sq_repack_linear_weight_f16": (_i, [_vp, _vp, _i, _i, _vp]),
     "sq_repack_rows_frag_f16": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "sq_add_rmsnorm_slabs_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
@@ -79,6 +79,9 @@ PROTOTYPES = {
     "sq_ar_ipc_open": (_i, [_vp, C.POINTER(_vp)]),
     "sq_ar_ipc_close": (_i, [_vp]),
     "sq_ar_status": (_i, [_vp, C.POINTER(_i)]),
+    "sq_ar_set_fault_word": (_i, [_vp, _vp]),
+    "sq_ar_shared_host_open": (_i, [C.c_char_p, C.c_size_t, _i, C.POINTER(_vp), C.POINTER(_vp)]),
+    "sq_ar_shared_host_close": (_i, [C.c_char_p, _vp, C.c_size_t]),
     "sq_allreduce_sum_f16": (_i, [_vp, C.c_size_t, _i, _i, C.POINTER(_vp), C.c_size_t, _i, _vp]),
     "sq_allreduce_sum_slabs_f16": (_i, [_vp, _i, _vp, C.c_size_t, _i, _i, C.POINTER(_vp), C.c_size_t, _i, _vp]),
     "sq_allgather_cols_f16": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(_vp), C.c_size_t, C.c_size_t, _vp]),
@@ -90,6 +93,12 @@ _lib = None
 
 class SequoiaNativeError(RuntimeError):
     pass
+
+
+# measurement aids outside the library's default surface (include/sequoia_hip.h: #ifdef SEQUOIA_BUILD_PROBES)
+PROBE_PROTOTYPES = {
+    "sq_linear_ts_prefetch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+}
 
 
 def load() -> C.CDLL:
@@ -114,6 +123,11 @@ def load() -> C.CDLL:
             raise SequoiaNativeError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in PROBE_PROTOTYPES.items():      # present only in a SEQUOIA_BUILD_PROBES=1 build
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

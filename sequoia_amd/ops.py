@@ -78,6 +78,21 @@ class HipOps:
                                          _ptr(count), max_count, dst_offset, zero_end, _ptr(dst_offset_dev),
                                          self._stream()), "sq_kv_compact_f16")
 
+    def kv_compact2(self, kv0, kv1, slots, count, max_count, dst_offset, dst_offset_dev=None):
+        """Both caches of a step (kv0, kv1: objects with k_cache / v_cache [L, 1, H, M, D]) rolled back in one launch."""
+        for kv in (kv0, kv1):
+            _need(kv.k_cache, torch.float16, "k_cache"); _need(kv.v_cache, torch.float16, "v_cache")
+        if max_count > 0:
+            _need(slots, torch.int32, "slots")
+        if count is not None:
+            _need(count, torch.int32, "count", contiguous=False)
+        a = []
+        for kv in (kv0, kv1):
+            h_kv, m, d = kv.k_cache.shape[-3:]
+            a += [kv.k_cache.data_ptr(), kv.v_cache.data_ptr(), kv.k_cache.shape[0], h_kv, m, d]
+        check(self.lib.sq_kv_compact2_f16(*a, _ptr(slots), _ptr(count), max_count, dst_offset, _ptr(dst_offset_dev),
+                                          self._stream()), "sq_kv_compact2_f16")
+
     def kv_clear(self, k_cache, v_cache, used_rows):
         _need(k_cache, torch.float16, "k_cache"); _need(v_cache, torch.float16, "v_cache")
         n_layers = k_cache.shape[0]

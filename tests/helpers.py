@@ -68,6 +68,21 @@ def assert_top_p_equal_up_to_ties(logits16, got16, want16, label=""):
     return ties
 
 
+def cdf_interval_distance(p16, token, u24):
+    """Distance (in probability mass) between the uniform u24 / 2^24 and the CDF interval of `token` under p16."""
+    from oracle import ops_np as O
+    import numpy as np
+    w = O._grid_int(np.where(np.isnan(p16), np.float16(0), p16)).astype(np.int64)
+    total = int(w.sum())
+    c = np.cumsum(w)
+    lo, hi = (int(c[token - 1]) if token > 0 else 0), int(c[token])
+    if hi <= lo:
+        return float("inf")                      # a token without mass can never be drawn
+    thr = (int(u24) * total) >> 24
+    d = 0 if lo <= thr < hi else min(abs(thr - lo), abs(thr - (hi - 1)))
+    return d / float(total)
+
+
 def state_dict_of(z, prefix):
     sd = {}
     for k in z.files:
@@ -251,7 +266,14 @@ def check_replay(steps, z, meta, logit_tol=None):
         # tolerance: logit_tol absolute plus 4 fp16 ulps of the value (the headline-dims logits reach |x| ~ 40, where one
         # fp16 ulp is 0.03)
         def excess(got, ref):
-            return float((np.abs(got - ref) - np.abs(ref) * 2.0 ** -8).max())
+            # top_p < 1: removed tokens are -inf on both sides; a token at the very cut may be kept by one run and removed
+            # by the other (the logits differ within tolerance): at most a few per row, compared where both are finite
+            fin = np.isfinite(got) & np.isfinite(ref)
+            one_sided = np.isfinite(got) != np.isfinite(ref)
+            assert one_sided.sum() <= max(2, got.shape[0] // 2), f"step {s}: {int(one_sided.sum())} tokens filtered on one side only"
+            if not fin.any():
+                return 0.0
+            return float((np.abs(np.where(fin, got, 0) - np.where(fin, ref, 0)) - np.abs(np.where(fin, ref, 0)) * 2.0 ** -8).max())
         dd = excess(rec["draft_logits"][internal][:, ::stride], ref_d[internal]) if internal else 0.0
         dt = excess(rec["target_logits"][ok][:, ::stride], ref_t[ok])
         assert dd <= logit_tol and dt <= logit_tol, f"step {s}: logits off by {dd:.4f} / {dt:.4f} beyond 4 ulps"
@@ -308,10 +330,13 @@ def _ancestors(c, parent):
 
 # Committed traces whose GPU replay is KNOWN to leave the reference at a step for a reason the test then proves:
 # F_specinfer draws 64 tokens per step by exact inverse CDF at recorded 24-bit uniforms; the GPU's draft logits differ from
-# the reference's CPU logits within the asserted tolerance, which moves every CDF boundary by ~1e-4 of mass, and one of the
-# trace's 256 uniforms falls inside such a sliver -- the native run draws the neighbouring token there.  The kernels are
-# exact on their own inputs (asserted: the oracle, fed the native logits, reproduces the native step token for token).
-KNOWN_INPUT_LIMITED = {"F_specinfer": "one iid draw lands within the logit tolerance of a CDF boundary"}
+# the reference's logits by an fp16 ulp (fused QKV / gate-up GEMMs), which moves every CDF boundary by up to 2 d / T of mass,
+# and some of the trace's 256 uniforms fall inside such a sliver -- the native run draws the neighbouring token there (the
+# CPU host loop on the oracle ops does the same at the same step).  Asserted instead: the kernels are exact on their own
+# inputs (the oracle, fed the native logits, reproduces the native step token for token), and every flipped draw sits
+# within the CDF shift its row's measured logit difference can cause.
+KNOWN_INPUT_LIMITED = {"F_specinfer": "iid draws land within the logit tolerance of a CDF boundary",
+                       "G_greedys": "iid target draws land within the logit tolerance of a CDF boundary"}
 
 
 def assert_replay_complete(name, steps, tree, z, meta, matched, diverged, commit_order="reference", committed=True):
@@ -377,9 +402,43 @@ def assert_replay_complete(name, steps, tree, z, meta, matched, diverged, commit
         ref_t = rec["ref_tokens_pre"][gt - 1:gt + n - 1]
         parent = {c: p for p, ch in enumerate(succ) for c in ch}
         first_diff = [c for c in range(1, n) if got_t[c] != ref_t[c] and all(got_t[a] == ref_t[a] for a in _ancestors(c, parent))]
-        assert same and len(first_diff) <= 1, (f"{name} step {diverged}: documented as '{known}', but the native step differs "
-                                               f"from the oracle on its own inputs or in {len(first_diff)} independent draws")
-        note_escape(f"{name} step {diverged}: {known}", 0.0)
+        assert same, f"{name} step {diverged}: documented as '{known}', but the native step differs from the oracle on its own inputs"
+        worst = 0.0
+        if mode == "greedys":
+            # GreedySTree: the TARGET token of every node is an inverse-CDF draw at a recorded uniform
+            ref_tt = z[f"step{diverged}/target_token"]
+            ref_tl = z[f"step{diverged}/target_logits"].astype(np.float32)
+            # only nodes whose token path equals the reference's see the reference's inputs (check_replay asserted their
+            # logits within tolerance); a node below a flipped draw legitimately differs
+            okset = {0}
+            for t in range(1, n):
+                if parent[t] in okset and got_t[t] == ref_t[t]:
+                    okset.add(t)
+            flipped = [t for t in sorted(okset) if int(tt[t]) != int(ref_tt[t])]
+            assert flipped, f"{name} step {diverged}: no differing target draw on a comparable node explains the divergence"
+            for t in flipped:
+                d_ = float(np.abs(rec["target_logits"][t].astype(np.float32) - ref_tl[t]).max())
+                q_ = O.scaled_softmax_f16(tl[t][None], T)[0]
+                dist = cdf_interval_distance(q_, int(ref_tt[t]), int(z["target_u24"][diverged][t]))
+                assert dist <= 2.0 * d_ / T + 2.0 ** -20, (f"{name} step {diverged}: the target draw of node {t} is {dist:.2e} of mass "
+                                                          f"away from the reference's token; the row's logits differ by {d_:.2e}")
+                worst = max(worst, dist)
+            note_escape(f"{name} step {diverged}: {known} ({len(flipped)} target draws, <= {worst:.1e} of mass from the reference's token)", worst)
+            return
+        assert mode == "specinfer" and first_diff, f"{name} step {diverged}: no differing draw explains the divergence"
+        ref_dl = z[f"step{diverged}/draft_logits_pre"].astype(np.float32)
+        for c in first_diff:
+            # PROOF that the input difference explains the flipped draw: under the native run's own draft row the
+            # reference's token sits within the CDF shift that the (measured) logit difference of that row can cause --
+            # a logit moving by d moves its probability by a factor e^(d / T): the CDF by at most 2 d / T of mass
+            p_, j_ = parent[c], succ[parent[c]].index(c)
+            d_ = float(np.abs(rec["draft_logits"][p_].astype(np.float32) - ref_dl[p_]).max())
+            q_ = O.scaled_softmax_f16(dl[p_][None], T)[0]
+            dist = cdf_interval_distance(q_, int(ref_t[c]), int(z["draw_u24"][diverged][p_][j_]))
+            assert dist <= 2.0 * d_ / T + 2.0 ** -20, (f"{name} step {diverged}: draw {j_} of node {p_} is {dist:.2e} of mass away "
+                                                      f"from the reference's token; the row's logits differ by {d_:.2e}")
+            worst = max(worst, dist)
+        note_escape(f"{name} step {diverged}: {known} ({len(first_diff)} draws, <= {worst:.1e} of mass from the reference's token)", worst)
         return
     if same:
         note_escape(f"{name} step {diverged}: inputs differ within the logit tolerance, kernels exact on their own inputs", 0.0)

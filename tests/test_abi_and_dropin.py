@@ -13,6 +13,15 @@ def test_library_exports_every_declared_symbol():
     from sequoia_amd import native
     lib = native.load()
     header = open(os.path.join(REPO, "include", "sequoia_hip.h")).read()
+    # measurement aids live behind SEQUOIA_BUILD_PROBES and are not part of the default surface
+    probes = re.findall(r"#ifdef SEQUOIA_BUILD_PROBES.*?#endif", header, flags=re.S)
+    probe_names = set(re.findall(r"\b(sq_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", " ", " ".join(probes), flags=re.S)))
+    assert probe_names == set(native.PROBE_PROTOTYPES)
+    from sequoia_amd.build import PROBES
+    if not PROBES:
+        for name in probe_names:
+            assert not hasattr(lib, name), f"{name} is a measurement aid: it must not be exported by a default build"
+    header = re.sub(r"#ifdef SEQUOIA_BUILD_PROBES.*?#endif", " ", header, flags=re.S)
     declared = set(re.findall(r"\b(sq_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     for name in sorted(declared):

@@ -79,6 +79,27 @@ def test_native_loop_follows_reference_trace(oracle_ops, name):
         assert np.array_equal(tree.position_ids.numpy(), z[f"step{last}/position_ids_post"])
 
 
+def test_commit_order_quirk_is_counted_not_silent(oracle_ops):
+    """The reference's store-before-gather order (Tree/SpecTree.py:222-224) commits the bonus id over an accepted token
+    whenever an accepted node sits at slot a; reproduced by default for token parity, but every such step is counted
+    (tree.quirk_steps / QUIRK_STEPS, printed by bench.py) -- trace_F_specinfer contains one (a fully accepted path) -- and
+    the lossless order never counts."""
+    from conftest import load_trace
+    from helpers import build_engines, make_tree
+    from sequoia_amd.Tree import _native_tree as NT
+    steps, tree, draft, target, z, meta = replay_trace("F_specinfer", "cpu")
+    assert tree.commit_order == "reference" and tree.quirk_steps >= 1 and NT.QUIRK_STEPS[0] >= tree.quirk_steps
+    z, meta = load_trace("F_specinfer")
+    draft, target = build_engines(z, meta, "cpu")
+    t2 = make_tree(z, meta, draft, target, "cpu")
+    t2.commit_order = "lossless"
+    for _ in range(int(z["n_steps"])):
+        t2.construct_grow_map()
+        if t2.verify()[3]:
+            break
+    assert t2.quirk_steps == 0
+
+
 def test_sample_iid_distribution():
     rng = np.random.default_rng(0)
     logits = (rng.standard_normal((1, 64)) * 2).astype(np.float16)

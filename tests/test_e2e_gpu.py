@@ -11,16 +11,17 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import COMPACT_TRACES, HEADLINE_TRACES, TRACE_NAMES, WIDTH_TRACES, load_trace
+from conftest import COMPACT_TRACES, HEADLINE_TRACES, TOPP_TRACES, TRACE_NAMES, WIDTH_TRACES, load_trace
 from helpers import assert_replay_complete, build_engines, check_replay, make_tree, replay_trace
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("name", TRACE_NAMES + COMPACT_TRACES + HEADLINE_TRACES + WIDTH_TRACES)
+@pytest.mark.parametrize("name", TRACE_NAMES + COMPACT_TRACES + TOPP_TRACES + HEADLINE_TRACES + WIDTH_TRACES)
 def test_gpu_loop_reproduces_reference_tokens(name):
-    """All steps of every trace (configs A-E shapes, the demo tree, the V = 32000 trace, and the two traces at the
+    """All steps of every trace (configs A-E shapes, the demo tree, the V = 32000 trace, the same pair under the harness's
+    default nucleus filter top_p = 0.9 -- sq_top_p_filter_f16 in front of the verifier --, and the two traces at the
     headline model dims: 68m -> Llama-2-7b architectures, SpecTree 128-node growmap and GreedyTree 8x8).  Logits agree within
     tolerance in every compared step (asserted inside check_replay); the committed tokens are identical in every
     step -- a stochastic run may leave the reference only at a decision whose margin is proven to be inside one fp16

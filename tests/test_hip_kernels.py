@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, STOCHASTIC_TRACES, load_trace
-from helpers import assert_top_p_equal_up_to_ties, note_escape, split_margin
+from helpers import assert_top_p_equal_up_to_ties, cdf_interval_distance, note_escape, split_margin
 from oracle import ops_np as O
 
 pytestmark = pytest.mark.gpu
@@ -105,6 +105,25 @@ def test_kv_scatter_compact_clear(ops, L, H, M, D):
     ops.kv_clear(dk, dv, 50)
     O.kv_clear(k[:, 0], v[:, 0], 50)
     assert np.array_equal(dk.cpu().numpy(), k) and np.array_equal(dv.cpu().numpy(), v)
+
+
+def test_kv_compact_two_caches_in_one_launch(ops):
+    """sq_kv_compact2_f16 (the device-driven step's roll-back of the draft AND the target cache) == two sq_kv_compact_f16
+    launches == the oracle, for caches of different layers / heads / head dims, with the destination read on the device."""
+    from types import SimpleNamespace
+    rng = np.random.RandomState(5)
+    shapes = [(2, 12, 384, 64), (4, 8, 384, 128)]            # 68m-like draft cache, GQA target cache
+    host = [(rng.randn(L, 1, H, M, D).astype(np.float16), rng.randn(L, 1, H, M, D).astype(np.float16)) for L, H, M, D in shapes]
+    gt = 130
+    for slots in ([gt, gt + 1, gt + 7, gt + 40], [gt + 3], []):
+        kvs = [SimpleNamespace(k_cache=dev(k), v_cache=dev(v)) for k, v in host]
+        ds = dev(np.asarray(slots if slots else [0], dtype=np.int32))
+        cnt = dev(np.asarray([len(slots)], dtype=np.int32))
+        gt_dev = dev(np.asarray([gt], dtype=np.int32))
+        ops.kv_compact2(kvs[0], kvs[1], ds, cnt, 8, 0, dst_offset_dev=gt_dev)
+        for (k, v), kv in zip(host, kvs):
+            O.kv_compact(k[:, 0], v[:, 0], slots, gt, 0)
+            assert np.array_equal(kv.k_cache.cpu().numpy(), k) and np.array_equal(kv.v_cache.cpu().numpy(), v), slots
 
 
 # ---- a3/a4 --------------------------------------------------------------------------------------
@@ -319,7 +338,7 @@ def test_verify_stochastic_random(ops, V, n, seed):
                 # in a few entries, which shifts the CDF by a few grid units -- the kernel's token must then be the
                 # oracle's draw for a uniform within that shift of the step's uniform (a neighbouring token with
                 # non-zero mass in CDF order).
-                assert _cdf_interval_distance(want["final_p"], int(res[2]), u24) <= 64 * 2.0 ** -24, \
+                assert cdf_interval_distance(want["final_p"], int(res[2]), u24) <= 64 * 2.0 ** -24, \
                     f"bonus token {int(res[2])} is not a CDF neighbour of the oracle's draw {want['bonus']}"
             a = want["accept_len"]
             assert np.array_equal(tok_after[:a], o_tokens[:a])
@@ -329,19 +348,6 @@ def test_verify_stochastic_random(ops, V, n, seed):
             assert m is not None and abs(m) < 1e-3, f"trial {trial}: paths split at a decision with margin {m}"
             note_escape(f"test_verify_stochastic_random V={V} n={n} seed={seed} trial {trial}", m)
     assert agree >= total - 1
-
-
-def _cdf_interval_distance(p16, token, u24):
-    """Distance (in probability mass) between the uniform u24 / 2^24 and the CDF interval of `token` under p16."""
-    w = O._grid_int(np.where(np.isnan(p16), np.float16(0), p16)).astype(np.int64)
-    total = int(w.sum())
-    c = np.cumsum(w)
-    lo, hi = (int(c[token - 1]) if token > 0 else 0), int(c[token])
-    if hi <= lo:
-        return float("inf")                      # a token without mass can never be drawn
-    thr = (int(u24) * total) >> 24
-    d = 0 if lo <= thr < hi else min(abs(thr - lo), abs(thr - (hi - 1)))
-    return d / float(total)
 
 
 def test_verify_stochastic_nan_and_eos(ops):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TRACE_NAMES
+from conftest import TOPP_TRACES, TRACE_NAMES
 from helpers import check_replay, replay_trace
 
 
@@ -22,7 +22,7 @@ def oracle_ops():
     ops.set_ops_for_testing(None)
 
 
-@pytest.mark.parametrize("name", TRACE_NAMES)
+@pytest.mark.parametrize("name", TRACE_NAMES + TOPP_TRACES)      # (+ V = 32000 under the harness's default top_p = 0.9: 30 s)
 def test_native_loop_reproduces_reference_trace(oracle_ops, name):
     steps, tree, draft, target, z, meta = replay_trace(name, "cpu")
     assert len(steps) == int(z["n_steps"])
@@ -109,3 +109,29 @@ def test_last_step_before_max_length_completes_and_the_next_is_refused(oracle_op
         assert tree._no_room is not None
         with pytest.raises(ValueError):
             tree.construct_grow_map()
+
+
+def test_loop_run_prompts_counts_whole_prompts_and_prefill_steps():
+    """harness.Loop.run_prompts (bench.py's `value_reference_metric`): whole prompts from the prefill-bearing first step to
+    max_new tokens, as tests/testbed.py:78-95 times them; the prefill steps and their wall time are accounted separately."""
+    from conftest import load_trace
+    from helpers import build_engines
+    from oracle.ops_adapter import OracleOps
+    from sequoia_amd import ops
+    from sequoia_amd.growmap import GrowMap
+    from sequoia_amd.harness import Loop
+    ops.set_ops_for_testing(OracleOps())
+    try:
+        z, meta = load_trace("demo4")
+        draft, target = build_engines(z, meta, "cpu")
+        gm = GrowMap.from_successors(meta["successors"])
+        cfg = dict(mode="stochastic", M=meta["M"])
+        prompts = [[int(t) for t in z["prompt"]], [int(t) for t in z["prompt"][::-1]]]
+        loop = Loop(cfg, draft, target, gm, "cpu", prompts, use_graphs=False, max_new=len(prompts[0]) + 12, vocab=meta["vocab"])
+        secs, toks, steps = loop.run_steps(2)                # leaves a prompt half-way
+        assert steps == 2 and loop.prefill_steps == 1 and loop.prompts_done == 0
+        secs, toks, steps = loop.run_prompts(2)
+        assert loop.prompts_done == 2 and loop.prefill_steps == 3 and loop.tree is None
+        assert steps >= 2 and toks >= 2 * 12 and 0 < loop.prefill_seconds <= secs + 1.0
+    finally:
+        ops.set_ops_for_testing(None)

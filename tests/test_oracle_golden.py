@@ -9,9 +9,9 @@ bit-exact for token / index / integer results, and within one fp16 ulp for proba
 import numpy as np
 import pytest
 
-from conftest import COMPACT_TRACES, GOLDEN, STOCHASTIC_TRACES, TRACE_NAMES, load_trace
+from conftest import COMPACT_TRACES, GOLDEN, STOCHASTIC_TRACES, TOPP_TRACES, TRACE_NAMES, load_trace
 
-COMPACT_STOCHASTIC = COMPACT_TRACES + ["B_7b", "D_13b_w4", "E_70b_w2"]        # + the headline-dims SpecTree trace (68m -> 7B dims)
+COMPACT_STOCHASTIC = COMPACT_TRACES + TOPP_TRACES + ["B_7b", "D_13b_w4", "E_70b_w2"]        # + the headline-dims SpecTree trace (68m -> 7B dims)
 from oracle import ops_np as O
 
 
@@ -129,6 +129,24 @@ def test_verify_stochastic_matches_reference_full_vocab(name):
     reference's accept length, committed tokens and bonus token; rejections (residual updates) must occur."""
     margins = check_compact_verify(*load_trace(name), name)
     assert sum(m <= 0 for m in margins) >= 3 and sum(m > 0 for m in margins) >= 3
+
+
+@pytest.mark.parametrize("name", TOPP_TRACES)
+def test_top_p_filter_on_the_rows_of_a_reference_trace(name):
+    """SpecTree at top_p = 0.9 (the harness default): the reference filtered the target rows in place; the trace keeps the
+    rows of the walked path raw and filtered.  The oracle's filter on the raw rows == the reference's filtered rows (up to
+    the identity of exactly equal logits at the cut), and -- test_verify_stochastic_matches_reference_full_vocab -- the
+    oracle's verifier on the filtered rows walks the reference's path in every step."""
+    from helpers import assert_top_p_equal_up_to_ties
+    z, meta = load_trace(name)
+    assert meta["top_p"] < 1.0
+    rows = 0
+    for s in range(int(z["n_steps"])):
+        raw, filt = z[f"step{s}/path_target_rows_raw"], z[f"step{s}/path_target_rows"]
+        assert np.isinf(filt).any() and not np.isinf(raw).any()
+        assert_top_p_equal_up_to_ties(raw, O.top_p_filter(raw, meta["top_p"], meta["T"]), filt, f"{name} step {s}")
+        rows += raw.shape[0]
+    assert rows >= 20
 
 
 def check_compact_verify(z, meta, name):

@@ -43,7 +43,9 @@ def _worker(rank, world, port, name, out_dir, device="cpu"):
         tokens_pre = tree.tokens.cpu().numpy().copy()
         dl = tree.draft_logits.float().cpu().numpy().copy()
         valid, a, _, term = tree.verify()
+        lr = tree.last_result
         steps.append(dict(valid=valid.cpu().numpy().copy(), accept_len=int(a), terminal=bool(term), tokens_pre=tokens_pre,
+                          slots=[int(x) for x in lr[64:64 + int(lr[1])]],
                           draft_logits=dl, target_logits=tree.target_logits.float().cpu().numpy().copy(),
                           ref_valid=z[f"step{s}/valid_tokens"], ref_tokens_pre=z[f"step{s}/tokens_pre"],
                           ref_accept_len=int(z[f"step{s}/accept_len"]), gt=int(z[f"step{s}/gt"])))
@@ -51,8 +53,9 @@ def _worker(rank, world, port, name, out_dir, device="cpu"):
     if diverged is not None:
         # a sharded sum rounds differently from the reference's unsharded fp16 GEMM: a decision may flip only where its
         # margin is inside one fp16 ulp -- the oracle on the native run's own inputs must agree with the native decisions
+        # (two ranks reproduce every committed trace: fail-closed; from 4-way sharded sums on, the escape of fresh inputs)
         from helpers import assert_replay_complete
-        assert_replay_complete(name, steps, tree, z, meta, matched, diverged)
+        assert_replay_complete(name, steps, tree, z, meta, matched, diverged, committed=world <= 2)
     # every rank must have taken identical decisions (replicated draft / verifier, no broadcast)
     mine = torch.tensor([s["accept_len"] for s in steps] + [int(steps[-1]["valid"][-1])])
     both = [torch.zeros_like(mine) for _ in range(world)]

@@ -18,6 +18,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
 
+@pytest.fixture(params=["device", "host"], autouse=True)
+def ws_mode(request, monkeypatch):
+    """Every test of this file runs twice: with the workspaces in uncached DEVICE memory shared through hipIpc (the
+    production form; on this one-GPU box both "peers" then share one HBM and one L2 fabric), and with the workspaces in
+    fine-grained HOST memory shared between the processes (SEQUOIA_AR_WS=host): every payload store, flag store and flag
+    poll then leaves the device over PCIe, so a missing system-scope fence, a flag overtaking its payload or a cached
+    flag read has a real chance to show -- the closest a one-GPU box gets to peer memory behind an xGMI link."""
+    monkeypatch.setenv("SEQUOIA_AR_WS", request.param)
+    return request.param
+
+
 def _ar_worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO); sys.path.insert(0, HERE)
     import time
@@ -195,10 +206,20 @@ def _lonely_worker(rank, world, port, out_dir):
     ar = XgmiAllReduce.create(None, "cuda:0", max_elems=4096, self_check=False)
     assert ar is not None
     if rank == 0:
+        from sequoia_amd.Engine import xgmi_allreduce as XA
         x = torch.ones(4096, dtype=torch.float16, device="cuda:0")
         ar(x)
         torch.cuda.synchronize()                         # returns: the spin is bounded
-        np.save(os.path.join(out_dir, "lonely.npy"), np.array([ar.status()]))
+        # ... and the timeout does not pass silently: the kernel ORed its bits into the pinned fault word, which the
+        # speculation loop tests at every step (raise_on_fault) -- no device read involved
+        fault = int(ar.fault[0])
+        raised = 0
+        try:
+            XA.raise_on_fault()
+        except XA.XgmiCollectiveTimeout:
+            raised = 1
+        np.save(os.path.join(out_dir, "lonely.npy"), np.array([ar.status(), fault, raised]))
+        ar.clear_fault()
     dist.barrier()
     ar.close()
     dist.destroy_process_group()
@@ -208,7 +229,8 @@ def test_missing_peer_times_out_instead_of_hanging(tmp_path, monkeypatch):
     monkeypatch.setenv("SEQUOIA_AR_SPIN_LIMIT", "200000")        # ~0.3 s instead of the production bound of a few seconds
     port = 34700 + (os.getpid() % 1500)
     mp.spawn(_lonely_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert int(np.load(tmp_path / "lonely.npy")[0]) & 1 == 1
+    status, fault, raised = (int(v) for v in np.load(tmp_path / "lonely.npy"))
+    assert status & 1 == 1 and fault & 1 == 1 and raised == 1
 
 
 @pytest.mark.parametrize("name,world,fused_norm", [("E_64x2", 2, "1"), ("E_70b_w2", 2, "1"), ("E_64x2", 4, "1"), ("demo4", 4, "1"),

@@ -49,8 +49,7 @@ if what in ("attn", "all"):
     for (name, H, Hkv, D, L, qn, gt) in [("target7b_verify", 32, 32, 128, 32, n, 160),
                                          ("target7b_prefill", 32, 32, 128, 32, 128 + n - 1, 128),
                                          ("draft68m_level", 12, 12, 64, 2, 34, 160), ("draft68m_1tok", 12, 12, 64, 2, 1, 160),
-                                         ("target70b_shard", 8, 1, 128, 80, 129, 160), ("target70b_shard_tp4", 16, 2, 128, 80, 129, 160),
-                                         ("target70b_shard_tp2", 32, 4, 128, 80, 129, 160)]:
+                                         ("target70b_shard", 8, 1, 128, 80, 129, 160), ("target70b_shard_tp2", 32, 4, 128, 80, 129, 160)]:
         q_slot0 = gt - 1 if qn in (n, 129) else (0 if qn > n else gt + 20)
         kv_len = q_slot0 + qn
         q = torch.randn(H, qn, D, device=dev).half()

@@ -25,8 +25,14 @@ int main(int argc, char** argv) {
     std::vector<int> ms;
     for (int i = 1; i < argc; ++i) ms.push_back(atoi(argv[i]));
     if (ms.empty()) ms = {48, 64, 128};
-    const Shape shapes[] = {{"qkv", 12288, 4096, 0, 0}, {"o+res", 4096, 4096, 0, 1}, {"gate_up+silu", 11008, 4096, 1, 0},
-                            {"down+res", 4096, 11008, 0, 1}, {"lm_head", 32000, 4096, 0, 0}};
+    // TS_ARCH=13b: the Llama-2-13b projection shapes (configuration D) instead of the 7B ones
+    const bool a13 = getenv("TS_ARCH") && !strcmp(getenv("TS_ARCH"), "13b");
+    const Shape shapes7[] = {{"qkv", 12288, 4096, 0, 0}, {"o+res", 4096, 4096, 0, 1}, {"gate_up+silu", 11008, 4096, 1, 0},
+                             {"down+res", 4096, 11008, 0, 1}, {"lm_head", 32000, 4096, 0, 0}};
+    const Shape shapes13[] = {{"qkv", 15360, 5120, 0, 0}, {"o+res", 5120, 5120, 0, 1}, {"gate_up+silu", 13824, 5120, 1, 0},
+                              {"down+res", 5120, 13824, 0, 1}, {"lm_head", 32000, 5120, 0, 0}};
+    const Shape* shapes_p = a13 ? shapes13 : shapes7;
+    std::vector<Shape> shapes(shapes_p, shapes_p + 5);
     const size_t slab_cap = 256ull << 20;
     void* slab; CK(hipMalloc(&slab, slab_cap));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -60,7 +66,7 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(dr, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
             // (tiles, splits) candidates
             std::vector<std::pair<int, int>> cands;
-            const int max_u = sh.silu ? 3 : 8;
+            const int max_u = sh.silu ? 4 : 8;
             for (int upt = (getenv("TS_MIN_U") ? atoi(getenv("TS_MIN_U")) : 1); upt <= max_u; ++upt)
                 for (int sp : {1, 2, 3, 4, 6, 8}) {
                     const int tiles = (units + upt - 1) / upt;
