@@ -593,7 +593,9 @@ def main():
                    draft_lm_scale=2.23)
     run_case(R, "B_7b", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), d68, t7b, 32000, 384, 0.6,
              "stochastic", 128, 4, 41, out_dir=out_dir, **knobs7b)
-    run_case(R, "C_7b", gm("L40_growmaps/8x8-tree.pt"), d68, t7b, 32000, 384, 0.6, "greedy", 128, 4, 41, out_dir=out_dir, **knobs7b)
+    # (7 steps: the 8 x 8 tree is 8 greedy chains -- a path deeper than 2 needs the draft's argmax to equal the target's at every
+    # level; steps 3 and 6 accept 5 and 3 tree tokens, the others 1-2)
+    run_case(R, "C_7b", gm("L40_growmaps/8x8-tree.pt"), d68, t7b, 32000, 384, 0.6, "greedy", 128, 7, 41, out_dir=out_dir, **knobs7b)
     # configuration D at its real WIDTHS (BASELINE.json configs[3]): Sheared-LLaMA-1.3B dims draft (hidden 2048, 16 heads of 128,
     # inter 5504) -> Llama-2-13b dims target (hidden 5120, 40 heads of 128, inter 13824), 4 layers each (the widths decide
     # the kernels' shapes and launch plans -- the 13B plans mix the tall-skinny kernel with hipBLASLt -- the depth only
@@ -603,6 +605,14 @@ def main():
     run_case(R, "D_13b_w4", gm("A100_growmaps/160m_13b/growmaps/A100-CNN-160m-13b-stochastic.pt"), d13w, t13w, 32000, 384, 0.6,
              "stochastic", 128, 4, 43, logit_gain=1.2, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.005,
              lead=(2048, 3.0), out_dir=out_dir)
+    # configuration D at FULL DEPTH (round 4): Sheared-LLaMA-1.3B dims (24 layers) -> Llama-2-13b dims (40 layers), 26 GB of
+    # seeded fp16 target weights, the same growmap, V = 32000, M = 384, 128-token prompt.  Knobs like the 7B pair's: lead
+    # dimensions at 8x, 2 % draft noise, draft lm_head at the ratio of the two RMSNorm scales (1.56), branches at 0.0015.
+    d13 = (2048, 5504, 24, 16, 16)
+    t13 = (5120, 13824, 40, 40, 40)
+    run_case(R, "D_13b", gm("A100_growmaps/160m_13b/growmaps/A100-CNN-160m-13b-stochastic.pt"), d13, t13, 32000, 384, 0.6,
+             "stochastic", 128, 4, 45, logit_gain=0.85, seeded=True, share_vocab=0.02, compact=16, branch_scale=0.0015,
+             lead=(2048, 8.0), draft_lm_scale=1.56, out_dir=out_dir)
     # configuration E at its real WIDTHS (BASELINE.json configs[4]): Llama-2-7b-dims draft -> Llama-2-70b-dims target (hidden
     # 8192, 64 query heads / 8 KV heads of 128: GQA 8:1, inter 28672), 2 layers each, the 129-node 64x2 tree (9 row tiles),
     # V = 32000: single GPU and tensor-parallel (KV-head split) replays

@@ -31,20 +31,24 @@ def _sync(device):
         torch.cuda.synchronize()
 
 
-# SpecTree / SpecInferTree commit order.  "reference" (default: this package is a drop-in, its token stream is the
-# reference's): the bonus token is stored BEFORE the accepted tokens are gathered, like Tree/SpecTree.py:222-224 -- an
-# accepted node sitting at slot gt + n_accepted (e.g. the root's second child accepted alone) is then committed with the
-# bonus token's id while its KV rows belong to the original token (an upstream quirk, a few percent of the steps on the
-# 128-node growmap; tests/test_properties_gpu.py::test_reference_commit_order_quirk).  "lossless": gather first, then
-# store the bonus token, so the committed text is exactly the accepted path (the algorithm as published):
-# SEQUOIA_COMMIT_ORDER=lossless, or `commit_order="lossless"` per tree.  bench.py prints the order it ran with
-# (`config.commit_order`) and times its CPU baseline with the same one.
-# The quirk is OBSERVABLE, not silent: every step that commits a bonus id over an accepted token is counted
-# (QUIRK_STEPS, tree.quirk_steps; bench.py prints the count) and the first one of a process raises a warning that names the
-# switch.  The KV rows are deliberately left alone: they are the accepted token's -- the context every later step
-# conditions on is the accepted path, only the reported id at that one position is off; rewriting the rows to match the
-# id would make the model state follow the glitch instead.
-COMMIT_ORDER = os.environ.get("SEQUOIA_COMMIT_ORDER", "reference")
+# SpecTree / SpecInferTree commit order.
+#   "lossless" (DEFAULT): the accepted tokens are gathered first, then the bonus token is stored -- the committed text is
+#       exactly the accepted path plus the bonus token, the algorithm as published.
+#   "reference": the bonus token is stored BEFORE the gather, like Tree/SpecTree.py:222-224 -- an accepted node that sits
+#       at slot gt + n_accepted (the root's (n_accepted + 1)-th child leading the accepted path: the root's second child
+#       accepted alone, its third child with one accepted descendant, ...) is then committed with the BONUS token's id
+#       while its KV rows belong to the token that was accepted.  An upstream bug, and not a rare one: 6 of the 20 timed
+#       steps of bench.py's driver run on the 128-node growmap (profiles/r04_*).  Reproducing it is what makes the token
+#       stream identical to the reference's, so every replay of a reference trace selects it explicitly
+#       (tests/helpers.py::make_tree) and anyone who needs the reference's stream sets SEQUOIA_COMMIT_ORDER=reference or
+#       passes commit_order="reference" per tree.  It is not the product default: a generation API should not emit ids the
+#       verifier never accepted (rounds 2-3 shipped "reference" as the default).
+#       In this mode the quirk is observable, not silent: every such step is counted (QUIRK_STEPS, tree.quirk_steps;
+#       bench.py prints config.commit_order_quirk_steps) and the first one of a process raises a warning.  The KV rows
+#       are left alone in both modes: they are the accepted token's -- the context later steps condition on is the
+#       accepted path; rewriting them to match the glitched id would make the model state follow the bug.
+# bench.py prints the order it ran with (`config.commit_order`) and times its CPU baseline with the same one.
+COMMIT_ORDER = os.environ.get("SEQUOIA_COMMIT_ORDER", "lossless")
 QUIRK_STEPS = [0]
 if COMMIT_ORDER not in ("reference", "lossless"):
     raise ValueError(f"SEQUOIA_COMMIT_ORDER must be 'reference' or 'lossless', got {COMMIT_ORDER!r}")

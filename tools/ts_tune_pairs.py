@@ -29,7 +29,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--arch", default="meta-llama/Llama-2-7b-hf")
 ap.add_argument("--rows", nargs="+", type=int, default=[128])
 ap.add_argument("--layers", type=int, default=8)
-ap.add_argument("--names", nargs="+", default=["o", "down"])
+ap.add_argument("--names", nargs="+", default=["o", "down"], help="o down qkv")
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 
@@ -67,8 +67,44 @@ def timeit(fn, n_layers, reps=16):
 
 
 report = {}
+
+
+def tune_qkv(q):
+    """qkv + the RoPE / KV-write launch that consumes it: split-K slabs (sq_rope_kv_write_slabs_f16 sums them) against fp16
+    rows (sq_rope_kv_write_f16)."""
+    n_out, k, _ = ts.shapes["qkv"]
+    H, Hkv, D, M = dims.local_heads, dims.local_kv_heads, dims.head_dim, 384
+    for li in range(args.layers):
+        ts.frag("qkv", li)
+    a = ops.repack_rows((torch.randn(q, k, device=dev) * 0.5).half())
+    rows = torch.empty((q, n_out), dtype=torch.float16, device=dev)
+    q_out = torch.empty((H, q, D), dtype=torch.float16, device=dev)
+    kc = torch.zeros((Hkv, M, D), dtype=torch.float16, device=dev); vc = torch.zeros_like(kc)
+    cos = torch.randn(2048, D, device=dev).half()
+    pos = torch.arange(130, 130 + q, device=dev)
+    res = {}
+    for tiles, splits in sorted(set(ts_linear.candidates(n_out, k, False, q, allow_split=True))):
+        if splits > 1:
+            def pair(li, tiles=tiles, splits=splits):
+                ops.linear_ts(a, ts.frag("qkv", li), q, n_out, k, tiles=tiles, splits=splits, slab=ts._slab)
+                ops.rope_kv_write_slabs(ts._slab, splits, n_out, q_out, kc, vc, cos, cos, pos, pos, H, Hkv, D)
+            res[f"{tiles}x{splits}:slab"] = (None, round(timeit(pair, args.layers), 2))
+        else:
+            def pair(li, tiles=tiles):
+                ops.linear_ts(a, ts.frag("qkv", li), q, n_out, k, out=rows, tiles=tiles, splits=1)
+                ops.rope_kv_write(rows, q_out, kc, vc, cos, cos, pos, pos, H, Hkv, D)
+            res[f"{tiles}x1:rows"] = (None, round(timeit(pair, args.layers), 2))
+    order = sorted(res.items(), key=lambda kv: kv[1][1])
+    key = f"qkv:{n_out}x{k}@{q}"
+    report[key] = dict(best=order[0][0], best_pair_us=order[0][1][1], all={k_: v for k_, v in order})
+    print(key, "best pair (projection + RoPE / KV write):", order[:6], flush=True)
+
+
 for q in args.rows:
     for name in args.names:
+        if name == "qkv":
+            tune_qkv(q)
+            continue
         n_out, k, _ = ts.shapes[name]
         assert n_out == hidden
         for li in range(args.layers):
