@@ -595,6 +595,10 @@ def main():
     ap.add_argument("--no-kernel-rooflines", action="store_true",
                     help="profiling aid: skip the per-kernel micro-timings (and with them `roofline` / `kernels`), so that a "
                          "rocprofv3 trace of this command contains the loop's own dispatches only")
+    ap.add_argument("--commit-order", default="reference", choices=["reference", "lossless"],
+                    help="the metric is the reference harness's (tests/testbed.py:45-95), so its loop runs the reference's commit "
+                         "order by default -- the token stream, and with it tokens/step of the timed window, is the reference's; "
+                         "the package's own default is `lossless` (Tree/_native_tree.py); steps/s is the same in both")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="single-GPU config B: skip the configs C and D runs that follow the headline (`other_configs`)")
     ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each `other_configs` run")
@@ -628,6 +632,8 @@ def main():
     torch.cuda.set_device(local)
     torch.manual_seed(17 + rank)
 
+    from sequoia_amd.Tree import _native_tree as _NT
+    _NT.COMMIT_ORDER = args.commit_order      # every tree built from here on (the loops, the CPU baseline) commits in this order
     cfg = dict(MODELS[args.config])
     if args.growmap:
         cfg["growmap"] = args.growmap
@@ -644,7 +650,8 @@ def main():
     loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs,
                 pipelined=not args.sync_loop and not args.no_graphs)
 
-    from sequoia_amd.Tree._native_tree import COMMIT_ORDER as commit_order, QUIRK_STEPS
+    from sequoia_amd.Tree._native_tree import QUIRK_STEPS
+    commit_order = args.commit_order
     loop.run_steps(args.warmup)
     QUIRK_STEPS[0] = 0           # counted over the timed steps only (config.commit_order_quirk_steps)
     if tp_mode and world > 1:
@@ -804,6 +811,9 @@ def main():
                                          f"prompts, generate to 256",
                                 parallelism=(f"tp{world}" if tp_mode else ("replicas" if world > 1 else "single")), graphs=not args.no_graphs,
                                 commit_order=commit_order, commit_order_quirk_steps=QUIRK_STEPS[0],
+                                commit_order_note="the reference harness's own order (its token stream, bonus-id quirk included, "
+                                                  "Tree/SpecTree.py:222-224); the package default is `lossless` -- same kernels, same "
+                                                  "steps/s, one flag bit in the walker",
                                 step_loop="device-driven (one hipGraph per speculation step, results read one step late)"
                                 if loop.pipelined else "host-driven (one result read per step)",
                                 gemm="tree forwards (<= 144 rows): sq_linear_ts_f16 (fragment-major weight stream, plans "

@@ -63,6 +63,9 @@ TOPP_TRACES = ["B_topp09"]
 # configuration D at its real widths (1.3B-dims draft -> 13B-dims target: hidden 5120, 40 heads, inter 13824), 4 layers each
 # configuration E at its real widths (7B-dims draft -> 70B-dims target: hidden 8192, GQA 64:8, inter 28672), 2 layers each
 WIDTH_TRACES = ["D_13b_w4", "E_70b_w2"]
+# configuration D at FULL DEPTH: Sheared-LLaMA-1.3B dims (24 layers) -> Llama-2-13b dims (40 layers), 26 GB of seeded weights
+# (two to three minutes of CPU generation on the GPU box, shared by the tests of one process)
+DEPTH_TRACES = ["D_13b"]
 BASELINE_TRACES = ["F_specinfer", "G_greedys"]        # the paper's comparison baselines (SpecInferTree, GreedySTree)
 
 

@@ -11,14 +11,14 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import COMPACT_TRACES, HEADLINE_TRACES, TOPP_TRACES, TRACE_NAMES, WIDTH_TRACES, load_trace
+from conftest import COMPACT_TRACES, DEPTH_TRACES, HEADLINE_TRACES, TOPP_TRACES, TRACE_NAMES, WIDTH_TRACES, load_trace
 from helpers import assert_replay_complete, build_engines, check_replay, make_tree, replay_trace
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("name", TRACE_NAMES + COMPACT_TRACES + TOPP_TRACES + HEADLINE_TRACES + WIDTH_TRACES)
+@pytest.mark.parametrize("name", TRACE_NAMES + COMPACT_TRACES + TOPP_TRACES + HEADLINE_TRACES + WIDTH_TRACES + DEPTH_TRACES)
 def test_gpu_loop_reproduces_reference_tokens(name):
     """All steps of every trace (configs A-E shapes, the demo tree, the V = 32000 trace, the same pair under the harness's
     default nucleus filter top_p = 0.9 -- sq_top_p_filter_f16 in front of the verifier --, and the two traces at the

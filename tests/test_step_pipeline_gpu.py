@@ -24,7 +24,7 @@ def _sync_run(z, meta, n_steps):
 
 
 @pytest.mark.parametrize("name", ["demo4", "B_seq128", "D_160m13b", "C_greedy8x8", "V32k_seq128", "B_topp09", "B_7b", "C_7b", "D_13b_w4",
-                                  "E_70b_w2"])
+                                  "E_70b_w2", "D_13b"])
 def test_step_graph_equals_synchronous_steps(name):
     z, meta = load_trace(name)
     n_steps = int(z["n_steps"])
