@@ -141,6 +141,13 @@ int sq_rope_kv_write_slabs_f16(const float* qkv_slab, int splits, int qkv_stride
                                const int64_t* d_position_ids, const int64_t* d_storage_ids, int q_len,
                                int n_heads, int h_kv, int d, int m, void* stream);
 
+/* Host-side view of sq_tree_attention_f16's block map (no device work): *n_blocks = the grid size for these head counts;
+ * for 0 <= block < *n_blocks, (head, 16-query tile) the block computes, or (-1, -1) for a block without work.  The map
+ * keeps every query tile of a KV head on one XCD (block % 8) -- on as few XCDs as give each workgroup a compute unit when
+ * there are fewer than 8 KV heads (tensor-parallel shards) -- and must cover every (head, tile) exactly once.
+ * block < 0 (or head / tile NULL): only *n_blocks is written.                                                          */
+int sq_tree_attention_block_decode(int block, int q_len, int n_heads, int h_kv, int* head, int* tile, int* n_blocks);
+
 /* Tree-batched attention for one layer (LlamaAttention_FI.forward Engine/Llama_modules.py:
  * 124-134 and LlamaAttention_TG.forward :220-248): out = softmax(q k^T * scale + mask) v over
  * key slots [0, kv_len), fp32 softmax, MFMA for q k^T and p v.

@@ -59,6 +59,36 @@ static inline int att_xcd_span(int n_heads, int h_kv, int n_tiles) {
     return want < 1 ? 1 : (want > budget ? budget : want);
 }
 
+// blockIdx.x -> (query head, query tile), or false for a block without work.  b % 8 selects the XCD (a speed hint: any
+// placement is correct).  One function for the kernel and for the host-side check of the map (sq_tree_attention_block_decode:
+// every (head, tile) exactly once, whatever the head counts -- tests/test_abi_and_dropin.py).
+__host__ __device__ static inline bool att_decode_block(int b, int n_heads, int h_kv, int n_tiles, int xcd_span, int* head, int* tile) {
+    const int xcd = b & 7, jj = b >> 3;
+    const int grp = n_heads / h_kv;
+    if (h_kv >= 8) {
+        // GQA with enough KV heads to fill the XCDs: all query heads of a KV head share its XCD
+        const int unit = grp * n_tiles;
+        const int kvh_x = xcd + 8 * (jj / unit), within = jj % unit;
+        if (kvh_x >= h_kv) return false;
+        *head = kvh_x * grp + within / n_tiles;
+        *tile = within % n_tiles;
+        return true;
+    }
+    // KV head kvh owns XCDs [kvh * budget, kvh * budget + span); its items (query head, tile) are dealt over them
+    const int budget = 8 / h_kv;
+    const int kvh_x = xcd / budget, j = xcd - kvh_x * budget;
+    const int item = jj * xcd_span + j;
+    if (kvh_x >= h_kv || j >= xcd_span || item >= grp * n_tiles) return false;
+    *head = kvh_x * grp + item / n_tiles;
+    *tile = item % n_tiles;
+    return true;
+}
+
+static inline int att_grid_blocks(int n_heads, int h_kv, int n_tiles, int xcd_span) {
+    return h_kv >= 8 ? 8 * ((h_kv + 7) / 8) * (n_heads / h_kv) * n_tiles
+                     : 8 * (((n_heads / h_kv) * n_tiles + xcd_span - 1) / xcd_span);
+}
+
 // max / sum over the four 16-lane groups holding the same query (lanes l, l^16, l^32, l^48) with the
 // gfx950 VALU lane swaps (v_permlane16_swap / v_permlane32_swap) instead of LDS-routed ds_bpermute
 // (inline asm: with ROCm 7.2's clang the __builtin_amdgcn_permlane*_swap builtins return the first
@@ -116,28 +146,12 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int qc = lane & 15, g = lane >> 4;
-    // XCD-aware decode: b % 8 selects the XCD; heads are dealt to XCDs round-robin, every query
-    // tile of a head shares its XCD (pure speed hint: any placement is correct).
+    // XCD-aware decode (att_decode_block): every query tile of a head -- of a KV head, under GQA -- shares its XCD's L2
     const int n_tiles = (P.q_len + ATT_BM - 1) / ATT_BM;
-    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int grp = P.n_heads / P.h_kv;
-    int head, q0;
-    if (P.h_kv >= 8) {
-        // GQA with enough KV heads to fill the XCDs: all query heads of a KV head share its XCD
-        const int unit = grp * n_tiles;
-        const int kvh_x = xcd + 8 * (jj / unit), within = jj % unit;
-        if (kvh_x >= P.h_kv) return;         // uniform per block
-        head = kvh_x * grp + within / n_tiles;
-        q0 = (within % n_tiles) * ATT_BM;
-    } else {
-        // KV head kvh owns XCDs [kvh * budget, kvh * budget + span); its items (query head, tile) are dealt over them
-        const int budget = 8 / P.h_kv;
-        const int kvh_x = xcd / budget, j = xcd - kvh_x * budget;
-        const int item = jj * P.xcd_span + j;
-        if (kvh_x >= P.h_kv || j >= P.xcd_span || item >= grp * n_tiles) return;       // uniform per block
-        head = kvh_x * grp + item / n_tiles;
-        q0 = (item % n_tiles) * ATT_BM;
-    }
+    int head, q_tile;
+    if (!att_decode_block(blockIdx.x, P.n_heads, P.h_kv, n_tiles, P.xcd_span, &head, &q_tile)) return;     // uniform per block
+    const int q0 = q_tile * ATT_BM;
     const int kvh = head / grp;
     const half_t* kbase = P.k + (size_t)kvh * P.m * D;
     const half_t* vbase = P.v + (size_t)kvh * P.m * D;
@@ -370,6 +384,19 @@ __global__ void __launch_bounds__(ATT_THREADS) tree_attention_kernel(AttnParams 
     }
 }
 
+// Host-side view of the launch's block map (no device work): the grid size of sq_tree_attention_f16 for these head counts,
+// and, for 0 <= block < *n_blocks, the (head, 16-query tile) the block computes (-1, -1: a block without work) and the XCD
+// it is expected on (block % 8).
+extern "C" int sq_tree_attention_block_decode(int block, int q_len, int n_heads, int h_kv, int* head, int* tile, int* n_blocks) {
+    if (q_len <= 0 || n_heads <= 0 || h_kv <= 0 || n_heads % h_kv || !n_blocks) return SQ_EINVAL;
+    const int n_tiles = (q_len + ATT_BM - 1) / ATT_BM;
+    const int span = h_kv < 8 ? att_xcd_span(n_heads, h_kv, n_tiles) : 0;
+    *n_blocks = att_grid_blocks(n_heads, h_kv, n_tiles, span);
+    if (block < 0 || block >= *n_blocks || !head || !tile) return block < 0 || !head || !tile ? SQ_OK : SQ_EINVAL;
+    if (!att_decode_block(block, n_heads, h_kv, n_tiles, span, head, tile)) { *head = -1; *tile = -1; }
+    return SQ_OK;
+}
+
 extern "C" int sq_tree_attention_f16(const void* q, const void* k_layer, const void* v_layer, void* out, int q_len,
                                      int n_heads, int h_kv, int d, int m, int kv_len, float scale, int mask_mode,
                                      const void* dense_mask, int mask_stride, int q_slot0, int gt, int n_tree,
@@ -401,9 +428,7 @@ extern "C" int sq_tree_attention_f16(const void* q, const void* k_layer, const v
     if (q_len == 0) return SQ_OK;
     const int n_tiles = (q_len + ATT_BM - 1) / ATT_BM;
     P.xcd_span = h_kv < 8 ? att_xcd_span(n_heads, h_kv, n_tiles) : 0;
-    const int blocks = h_kv >= 8 ? 8 * ((h_kv + 7) / 8) * (n_heads / h_kv) * n_tiles
-                                 : 8 * (((n_heads / h_kv) * n_tiles + P.xcd_span - 1) / P.xcd_span);
-    dim3 grid(blocks), block(ATT_THREADS);
+    dim3 grid(att_grid_blocks(n_heads, h_kv, n_tiles, P.xcd_span)), block(ATT_THREADS);
     hipStream_t st = (hipStream_t)stream;
     const int mk = mask_mode == 0 ? 0 : (P.words <= 2 ? 1 : 2);
 #define SQ_ATT(DD, MM) hipLaunchKernelGGL((tree_attention_kernel<DD, MM>), grid, block, 0, st, P)

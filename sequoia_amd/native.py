@@ -38,6 +38,7 @@ PROTOTYPES = {
     "sq_kv_clear_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_rope_kv_write_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sq_rope_kv_write_slabs_f16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sq_tree_attention_block_decode": (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "sq_tree_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _i, _i, _i,
                                    _vp, _i, _vp, _vp]),
     "sq_store_i32": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),

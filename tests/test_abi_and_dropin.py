@@ -110,3 +110,37 @@ def test_model_spec_errors_are_loud():
         parse_model_spec("meta-llama/Llama-2-7b-hf")
     kind, (arch, opts) = parse_model_spec("random:JackFram/llama-68m:seed=3")
     assert kind == "random" and arch == "JackFram/llama-68m" and opts["seed"] == "3"
+
+
+def test_attention_block_map_covers_every_tile_once_and_keeps_kv_heads_on_few_xcds():
+    """sq_tree_attention_block_decode = the kernel's own blockIdx -> (head, query tile) function (att_decode_block, shared by
+    host and device code): for every head configuration of the bundled models, tensor-parallel shards (fewer than 8 KV
+    heads, down to ONE for the 70B target at TP = 8) and odd test shapes, every (head, tile) is computed by exactly one
+    block, and the blocks of one KV head sit on the XCDs (block % 8) the design says: one XCD for >= 8 KV heads, at most
+    ceil(items / 32) -- never more than the head's 8 / h_kv share -- below that."""
+    import ctypes as C
+    from sequoia_amd import native
+    lib = native.load()
+    cases = [(32, 32), (40, 40), (12, 12), (16, 16), (64, 8), (8, 1), (16, 2), (32, 4), (8, 8), (4, 4), (2, 2), (5, 5), (4, 1), (6, 3), (7, 7),
+             (1, 1), (24, 8), (9, 3)]
+    for n_heads, h_kv in cases:
+        for q_len in (1, 16, 17, 34, 64, 128, 129, 144, 255):
+            n_tiles = (q_len + 15) // 16
+            nb = C.c_int(0)
+            assert lib.sq_tree_attention_block_decode(-1, q_len, n_heads, h_kv, None, None, C.byref(nb)) == 0
+            seen, xcds = {}, {}
+            for b in range(nb.value):
+                h, t = C.c_int(0), C.c_int(0)
+                assert lib.sq_tree_attention_block_decode(b, q_len, n_heads, h_kv, C.byref(h), C.byref(t), C.byref(nb)) == 0
+                if h.value < 0:
+                    continue
+                assert 0 <= h.value < n_heads and 0 <= t.value < n_tiles
+                assert (h.value, t.value) not in seen, (n_heads, h_kv, q_len, b)
+                seen[(h.value, t.value)] = b
+                xcds.setdefault(h.value // (n_heads // h_kv), set()).add(b % 8)
+            assert len(seen) == n_heads * n_tiles, (n_heads, h_kv, q_len, len(seen))
+            items = (n_heads // h_kv) * n_tiles
+            for kvh, xs in xcds.items():
+                want = 1 if h_kv >= 8 else max(1, min(8 // h_kv, (items + 31) // 32))
+                assert len(xs) <= want, (n_heads, h_kv, q_len, kvh, xs)
+            assert nb.value <= 8 * ((n_heads * n_tiles + 7) // 8 + n_tiles * max(1, n_heads // h_kv) * 8), "grid far larger than the work"

@@ -13,7 +13,7 @@ run_ts() {   # tag arch rows shape tiles splits
     TS_ARCH=$2 TS_ONLY="$4" TS_TILES=$5 TS_SPLITS=$6 timeout 200 rocprofv3 --kernel-trace --pmc $pass -d $OUT/ts_$1_$tagp -o r -- $GRAFT_REPO_ROOT/tools/ts_bench $3 > $OUT/ts_$1_$tagp.log 2>&1
   done
 }
-run_ts qkv 7b 128 qkv 256 1
+run_ts qkv 7b 128 qkv 128 2
 run_ts o 7b 128 "o+res" 64 4
 run_ts gate_up 7b 128 "gate_up+silu" 230 1
 run_ts down 7b 128 "down+res" 64 4

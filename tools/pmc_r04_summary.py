@@ -49,8 +49,8 @@ def add(key, *a):
         print(f"{key}: no record ({e})")
 
 
-add("qkv@8:256x1", "ts_qkv", "ts_linear_kernel<8, 3, 4, false>", 65536, "7B qkv 12288x4096, 128 rows, tiles 256, fp16 rows out (pair-tuned with RoPE / KV write)",
-    12288 * 4096 * 2 + M * 4096 * 2 + M * 12288 * 2)
+add("qkv@8:128x2", "ts_qkv", "ts_linear_kernel<8, 6, 3, false>", 65536, "7B qkv 12288x4096, 128 rows, tiles 128 x splits 2 (fp32 slabs)",
+    12288 * 4096 * 2 + M * 4096 * 2 + 2 * M * 12288 * 4)
 add("o@8:64x4", "ts_o", "ts_linear_kernel<8, 4, 3, false>", 65536, "7B o_proj 4096x4096, 128 rows, tiles 64 x splits 4",
     4096 * 4096 * 2 + M * 4096 * 2 + 4 * M * 4096 * 4)
 add("gate_up@8:230x1", "ts_gate_up", "ts_linear_kernel<8, 6, 3, true>", 58880, "7B gate_up 2x11008x4096 + SwiGLU, 128 rows, tiles 230",
