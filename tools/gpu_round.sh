@@ -6,17 +6,19 @@
 #          bench.py refuses a record measured on other sources, so this comes BEFORE the bench stage
 #   bench  the default line (with `other_configs` C / D), the driver's command, rocprofv3 --kernel-trace --stats of the default command
 #   loop   rocprofv3 --kernel-trace --stats of the loop alone (--no-kernel-rooflines)
+#   soak   3000 steps of the headline loop
 #   tp2    configuration E tensor-parallel with two ranks on the ONE GPU (xGMI kernels over hipIpc-mapped buffers)
+#   tp8    (not in the default set) the same with EIGHT ranks time-sliced on the one GPU: functional check of the TP = 8 plans / collectives
 # Everything is written under gpurun_out/<tag>/ (created first: a redirect into a missing directory silently skips a stage);
 # gpurun merges that directory back.  Afterwards, LOCALLY:   bash tools/gpu_round.sh r04 collect
 # copies the records the judge reads into profiles/<tag>_* (profiles/ written on the GPU box does not come back).
 TAG=${1:-r04}; shift
-STAGES="$*"; [ -z "$STAGES" ] && STAGES="tests pmc bench loop tp2"
+STAGES="$*"; [ -z "$STAGES" ] && STAGES="tests pmc bench loop soak tp2"
 if [ "$STAGES" = "collect" ]; then          # local: gpurun_out/<tag>/ -> profiles/<tag>_*
   cd "$(dirname "$0")/.." && O=gpurun_out/$TAG
   for pair in pmc.json:pmc.json bench_default.json:bench_default.json bench_driver_cmd.json:bench_driver_cmd.json \
               kernel_stats.md:bench_kernel_stats.md \
-              kernel_stats_loop_only.md:bench_kernel_stats_loop_only.md benchE_tp2.json:bench_configE_tp2_one_gpu.json; do
+              kernel_stats_loop_only.md:bench_kernel_stats_loop_only.md benchE_tp2.json:bench_configE_tp2_one_gpu.json benchE_tp8.json:bench_configE_tp8_functional_one_gpu.json bench_soak.json:bench_soak_3000steps.json; do
     src=$O/${pair%%:*}; [ -s $src ] && cp $src profiles/${TAG}_${pair##*:} && echo "profiles/${TAG}_${pair##*:}"
   done
   exit 0
@@ -62,6 +64,12 @@ if has loop; then
   (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_loop -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 120 --warmup 8 --no-kernel-rooflines --no-cpu-baseline --no-tuned-growmap --no-autoregressive --no-other-configs --no-reference-metric > $O/prof_loop.log 2>&1)
   python tools/rocprof_summary.py $(find $O/prof_loop -name "*results.db" | head -1) 40 > $O/kernel_stats_loop_only.md; find $O/prof_loop -name "*.db" -delete
   head -16 $O/kernel_stats_loop_only.md
+fi
+if has soak; then      # a long run of the headline loop: long-run tokens / step of the synthetic pair, no drift, no hang
+  timeout 600 python bench.py --steps 3000 --warmup 8 --no-cpu-baseline --no-autoregressive --no-tuned-growmap --no-other-configs --no-reference-metric > $O/bench_soak.json 2> $O/bench_soak.err; line $O/bench_soak.json
+fi
+if has tp8; then       # functional only: EIGHT tensor-parallel ranks time-sliced on the ONE GPU (times mean nothing)
+  SEQUOIA_TS_EXCLUSIVE=1 SEQUOIA_BENCH_ONE_DEVICE=1 timeout 900 python bench.py --gpus 8 --config E --backend gloo --steps 4 --warmup 2 --no-cpu-baseline --no-autoregressive > $O/benchE_tp8.json 2> $O/benchE_tp8.err; line $O/benchE_tp8.json; tail -3 $O/benchE_tp8.err
 fi
 if has tp2; then
   SEQUOIA_TS_EXCLUSIVE=1 SEQUOIA_BENCH_ONE_DEVICE=1 timeout 700 python bench.py --gpus 2 --config E --backend gloo --steps 8 --warmup 2 --no-cpu-baseline --no-autoregressive > $O/benchE_tp2.json 2> $O/benchE_tp2.err; line $O/benchE_tp2.json
