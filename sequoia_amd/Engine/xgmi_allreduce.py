@@ -41,10 +41,15 @@ def raise_on_fault():
     """Called by the speculation loop once per step (Tree/_native_tree.py::verify / collect_step): a collective kernel whose
     bounded spin ran out has continued on stale data -- every token decided after that is wrong, so the job stops here.
     Costs a read of one word of pinned host memory per live instance; nothing when no instance exists."""
+    dead = False
     for ref in _LIVE:
         ar = ref()
-        if ar is not None:
+        if ar is None:
+            dead = True
+        else:
             ar.check_fault()
+    if dead:
+        _LIVE[:] = [r for r in _LIVE if r() is not None]
 
 
 class XgmiAllReduce:
@@ -303,6 +308,7 @@ class XgmiAllReduce:
         return int(st.value)
 
     def close(self):
+        _LIVE[:] = [r for r in _LIVE if r() is not None and r() is not self]
         if self._shared is not None:
             sh, self._shared = self._shared, None
             torch.cuda.synchronize(self.device)
