@@ -500,6 +500,10 @@ def main_live(specs, out_dir):
         if mode == "stochastic":
             run_case(R, f"live_stochastic_{seed}", gm("demo_tree.pt"), tiny, gqa_t, 1024, 96, 0.6, "stochastic", 12, 6, seed,
                      out_dir=out_dir)
+        elif mode == "topp":
+            # SpecTree under the harness's default nucleus filter (tests/testbed.py:28: --P 0.9) on a correlated tiny pair
+            run_case(R, f"live_topp_{seed}", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "stochastic", 20, 4, seed,
+                     logit_gain=8.0, share_weights=0.05, top_p=0.9, out_dir=out_dir)
         elif mode == "sequoia128":
             run_case(R, f"live_sequoia128_{seed}", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), tiny, tiny,
                      1024, 256, 0.6, "stochastic", 24, 2, seed, logit_gain=8.0, share_weights=0.05, out_dir=out_dir)

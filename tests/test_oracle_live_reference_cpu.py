@@ -118,7 +118,8 @@ def test_tree_search_against_the_live_script(seed):
 
 
 # ---- fresh traces of the reference's SpecTree / GreedyTree (seeds outside the committed fixtures) ---------------------------
-LIVE_SPECS = ["live:stochastic:301", "live:stochastic:302", "live:sequoia128:303", "live:greedy:304"]
+LIVE_SPECS = ["live:stochastic:301", "live:stochastic:302", "live:sequoia128:303", "live:greedy:304",
+              "live:topp:310"]     # (+ SpecTree under the harness's default nucleus filter top_p = 0.9)
 BASELINE_SPECS = ["live:specinfer:305", "live:greedys:306"]          # the paper's comparison baselines
 PROBE_SPECS = ["live:spectest:307", "live:greedytest:308"]           # the acceptance-rate probes
 VOCAB_SPECS = ["live:v32k:309"]            # the real vocabulary: 68m-dims -> 160m-dims, config B's growmap, seeded weights, compact logits
