@@ -240,6 +240,9 @@ class TsLinearSet:
         ops = get_ops()
         n_out, k, silu = self.shapes[name]
         n_layers = 1 if name == "lm_head" else len(self.W.layers)
+        # images that exist BEFORE this call belong to other plans -- and, through them, to hipGraphs that were captured
+        # with their addresses: they must outlive this call whatever it decides (see the end of the function)
+        had_images = {li for li in range(n_layers) if (name, li) in self._frag}
         dev = self.device
         x = (torch.randn(q_len, k, device=dev) * 0.5).half()
         xf = ops.repack_rows(x)
@@ -299,9 +302,14 @@ class TsLinearSet:
             best, t_best = best_ts, t_ts
         key = plan_key(n_out, k, silu, (q_len + 15) // 16)
         self.tuned[key] = dict(choice=best, us=round(t_best, 2), torch_us=round(t_torch, 2), q_len=q_len, ts_us=results)
-        if best == "torch":                                  # drop images that will not be used
+        if best == "torch":
+            # Drop the images this call made for the measurement -- and ONLY those.  Round 4 found the use-after-free the
+            # unconditional pop was: a forward at a new row count (the 129-row prefill of a 2-node tree in
+            # growmap_tuning --config D) autotunes, PyTorch's GEMM wins, the pop frees the images of ALL row counts, and the
+            # hipGraph captured earlier for another row count replays on freed memory (GPU memory access fault).
             for li in range(n_layers):
-                self._frag.pop((name, li), None)
+                if li not in had_images:
+                    self._frag.pop((name, li), None)
         return best
 
 

@@ -67,6 +67,12 @@ def _sync():
     torch.cuda.synchronize()
 
 
+def _progress(msg: str):
+    """Stage markers on stderr (a tuning run takes minutes and ends on one JSON line)."""
+    import sys
+    print(f"growmap_tuning: {msg}", file=sys.stderr, flush=True)
+
+
 def measure_autoregressive_time(cfg, target, device, prompts, n_prompts: int = 2) -> float:
     """Seconds per token of the target-only baseline (harness.AutoregressiveLoop = simulation_baseline,
     tests/testbed.py:99-143)."""
@@ -84,6 +90,7 @@ def measure_step_times(cfg, draft, target, device, prompts, budgets, p_vec, max_
     for b in budgets:
         depth = int(np.argmax(tab.best[b] / (np.arange(max_depth + 1) * 0.02 + 1.0)))      # mild depth penalty
         gm = GrowMap.from_successors(tree_search.build_growmap(tab, b, depth)["Successors"])
+        _progress(f"step times: budget {b} (depth {depth}, level sizes {[lv.total for lv in gm.levels]})")
         loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=True, T=T, vocab=vocab)
         t_grow = t_verify = 0.0
         done = 0
@@ -137,8 +144,10 @@ def tune(config_name: str = "B", pair: str = "calibrated", device: str = "cuda:0
             p_vec[:width + 1] = a.numpy()
             p_vec[width + 1] = max(0.0, 1.0 - float(a.sum()))
         else:
+            _progress(f"acceptance vector: {accept_steps} steps on a {width}-child star tree")
             p_vec = measure_acceptance_vector(cfg, draft, target, device, prompts, width, accept_steps)
         draft.clear_kv(); target.clear_kv()
+        _progress("autoregressive baseline")
         t_ar = measure_autoregressive_time(cfg, target, device, prompts)
         d_time, t_time, detail = measure_step_times(cfg, draft, target, device, prompts, list(budgets), p_vec,
                                                     max_depth, time_steps)

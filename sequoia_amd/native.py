@@ -129,8 +129,34 @@ def load() -> C.CDLL:
         if fn is not None:
             fn.restype = res
             fn.argtypes = args
+    if os.environ.get("SEQUOIA_TRACE_CALLS", "0") == "1":
+        lib = _TracedLib(lib)
     _lib = lib
     return lib
+
+
+class _TracedLib:
+    """Debug aid (SEQUOIA_TRACE_CALLS=1): every C-ABI call is announced on stderr BEFORE it runs and followed by a device
+    synchronisation, so that a GPU memory fault (which aborts the process asynchronously) names the entry point it happened
+    in.  Orders of magnitude slower; never on by default."""
+
+    def __init__(self, lib):
+        object.__setattr__(self, "_lib", lib)
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("sq_") or name in ("sq_last_error", "sq_version", "sq_device_ready"):
+            return fn
+        import sys
+
+        def call(*a):
+            print(f"sq-call {name}{tuple(x if isinstance(x, (int, float)) else type(x).__name__ for x in a)}", file=sys.stderr, flush=True)
+            rc = fn(*a)
+            import torch
+            if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()
+            return rc
+        return call
 
 
 def check(rc: int, what: str) -> None:

@@ -259,6 +259,29 @@ def test_autotune_returns_a_usable_plan_and_never_runs_inside_a_capture():
     assert all(v is None for v in p.values()) and 33 not in ts._plans
 
 
+def test_autotune_never_frees_weight_images_that_existed_before_it(monkeypatch):
+    """The fragment-major weight images of a projection are shared by all its launch plans and referenced by every hipGraph
+    captured on them.  An autotune run for a NEW row count that ends on "torch" must therefore only drop the images it
+    made itself: round 4 hit the use-after-free (a 129-row prefill autotuned after the 2-row verify graph had been
+    captured; PyTorch's GEMM won; all images of that projection were freed; the graph replayed on freed memory)."""
+    from sequoia_amd.Engine import ts_linear
+    from sequoia_amd.Engine.Llama_model import LlamaDims, LlamaWeights
+    cfg = dict(vocab_size=2048, hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+               num_key_value_heads=2, max_position_embeddings=2048)
+    W = LlamaWeights.random(LlamaDims.from_any(cfg), torch.float16, DEV, 1)
+    ts = ts_linear.TsLinearSet(W, W.dims)
+    before = {}
+    for name in ("qkv", "gate_up"):
+        for li in range(2):
+            before[(name, li)] = ts.frag(name, li).data_ptr()          # images in use by some plan / captured graph
+    monkeypatch.setattr(ts_linear, "candidates", lambda *a, **k: [])    # no kernel candidate: PyTorch's GEMM "wins"
+    for name in ts.NAMES:
+        assert ts.autotune(name, 129) == "torch"
+    for key, ptr in before.items():
+        assert key in ts._frag and ts._frag[key].data_ptr() == ptr, f"{key}: image freed or moved by an autotune run"
+    assert ("o", 0) not in ts._frag and ("lm_head", 0) not in ts._frag   # nothing new is kept for a "torch" decision
+
+
 def test_plan_candidates_respect_kernel_limits():
     from sequoia_amd.Engine.ts_linear import candidates
     for n_out, k, silu, m in [(12288, 4096, False, 128), (11008, 4096, True, 48), (11008, 4096, True, 128), (768, 3072, False, 34),
