@@ -287,6 +287,26 @@ def run_other_config(name, args, device, prompts, engines=None, steps=20, warmup
                kernels={k: dict(avg_us=round(v["seconds"] * 1e6, 2), per_step_us=round(per_step[k] * 1e6, 1),
                                 frac=round(v["bytes"] / v["seconds"] / 8e12, 4), plan=v.get("plan")) for k, v in kr.items()},
                seconds_total=round(time.perf_counter() - t0, 1))
+    tuned_names = {"D": "MI355X-synthetic-1.3b-13b-stochastic"}
+    if name in tuned_names:
+        # the growmap sequoia_amd.growmap_tuning searched for this GPU and this (synthetic) model pair, like `mi355x_growmap` of
+        # the headline: the config's `value` stays on the growmap BASELINE.json names
+        try:
+            from sequoia_amd.growmap import GrowMap
+            gm2 = GrowMap.load(tuned_names[name])
+            draft.clear_kv(); target.clear_kv()
+            torch.manual_seed(17)
+            loop2 = Loop(cfg, draft, target, gm2, device, prompts, use_graphs=not args.no_graphs,
+                         pipelined=not args.sync_loop and not args.no_graphs)
+            loop2.run_steps(warmup)
+            torch.cuda.synchronize()
+            s2, t2, k2 = loop2.run_steps(steps)
+            torch.cuda.synchronize()
+            out["mi355x_growmap"] = dict(growmap=tuned_names[name], nodes=gm2.size, levels=[lv.total for lv in gm2.levels],
+                                         value=t2 / s2, unit="tokens/s", ms_per_step=s2 / k2 * 1e3, mean_accepted_len=t2 / k2, steps=k2)
+            del loop2
+        except Exception as e:
+            out["mi355x_growmap"] = dict(error=f"{type(e).__name__}: {e}")
     if name == "D":
         pk = None
         if dom.startswith("linear_ts_") and d.get("plan"):

@@ -3,7 +3,8 @@ cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r04/exp5
 mkdir -p $O
 export PYTHONUNBUFFERED=1
-timeout 900 python -m sequoia_amd.growmap_tuning --config D --out $O/MI355X-synthetic-1.3b-13b-stochastic.json > $O/tune_d.log 2> $O/tune_d.err; tail -2 $O/tune_d.log; tail -3 $O/tune_d.err
+timeout 300 python -m pytest tests/test_ts_linear_gpu.py -m gpu -q -k "autotune" > $O/tests_autotune.log 2>&1; tail -2 $O/tests_autotune.log
+timeout 900 python -m sequoia_amd.growmap_tuning --config D --out $O/MI355X-synthetic-1.3b-13b-stochastic.json > $O/tune_d.log 2> $O/tune_d.err; tail -2 $O/tune_d.log | cut -c1-1500; tail -3 $O/tune_d.err | cut -c1-300
 COMMON="--config D --steps 200 --warmup 6 --no-cpu-baseline --no-autoregressive --no-other-configs --no-reference-metric --no-tuned-growmap"
 timeout 600 python bench.py $COMMON > $O/bench_D_reference_growmap.json 2> $O/bench_D_ref.err
 timeout 600 python bench.py $COMMON --growmap $O/MI355X-synthetic-1.3b-13b-stochastic.json > $O/bench_D_mi355x_growmap.json 2> $O/bench_D_tuned.err
@@ -16,5 +17,3 @@ for f in ("bench_D_reference_growmap", "bench_D_mi355x_growmap"):
     except Exception as e:
         print(f, "failed", e)
 PY
-# the xGMI collective tests once more (Python-side registry change), both workspace modes
-timeout 900 python -m pytest tests/test_xgmi_allreduce_gpu.py -m gpu -q > $O/tests_xgmi.log 2>&1; tail -3 $O/tests_xgmi.log
