@@ -596,7 +596,7 @@ def main():
     knobs7b = dict(logit_gain=1.0, seeded=True, share_vocab=0.02, compact=16, branch_scale=0.0015, lead=(768, 8.0),
                    draft_lm_scale=2.23)
     run_case(R, "B_7b", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), d68, t7b, 32000, 384, 0.6,
-             "stochastic", 128, 4, 41, out_dir=out_dir, **knobs7b)
+             "stochastic", 128, 8, 41, out_dir=out_dir, **knobs7b)
     # (7 steps: the 8 x 8 tree is 8 greedy chains -- a path deeper than 2 needs the draft's argmax to equal the target's at every
     # level; steps 3 and 6 accept 5 and 3 tree tokens, the others 1-2)
     run_case(R, "C_7b", gm("L40_growmaps/8x8-tree.pt"), d68, t7b, 32000, 384, 0.6, "greedy", 128, 7, 41, out_dir=out_dir, **knobs7b)
