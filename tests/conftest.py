@@ -42,6 +42,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
                                 "draws of the baseline traces F_specinfer / G_greedys)")
     for label, m in esc:
         terminalreporter.write_line(f"  {label}: margin {m:.3e}")
+    if helpers.LOGIT_EXCESS:
+        terminalreporter.write_line("logit distance to the reference's recorded logits beyond 4 fp16 ulps (draft / target / tolerance):")
+        for (name, layers), (dd, dt, tol) in sorted(helpers.LOGIT_EXCESS.items()):
+            terminalreporter.write_line(f"  {name} ({layers} target layers): {dd:.4f} / {dt:.4f} / {tol:.4f}")
 
 
 def load_trace(name):

@@ -16,6 +16,10 @@ from sequoia_amd.native import SQ_RES_N_TREE, SQ_RESULT_INTS
 # inputs (random trees, live traces of the reference) may leave the oracle, and only at the ONE decision where the two
 # accepted paths part, with that decision's own margin below 1e-3 (split_margin).
 ESCAPES: list = []
+# (trace, target layers) -> (largest draft-logit excess, largest target-logit excess, tolerance) seen by check_replay: the
+# measured distance between this build's logits and the reference's recorded ones, beyond 4 fp16 ulps of the value --
+# printed in the session summary so that the tolerance is a number next to its evidence
+LOGIT_EXCESS: dict = {}
 
 
 def note_escape(label, margin):
@@ -225,11 +229,14 @@ def replay_trace(name, device, max_steps=None, trace=None):
 
 
 def depth_tolerance(meta, base=4e-2):
-    """Logit tolerance of a replay against the reference's CPU run: `base` (a few fp16 ulps at |logit| ~ 8) for the
-    2-12-layer trace models; every decoder layer adds two fp16 roundings of the residual stream, independent between the
-    two runs, so the tolerance grows with sqrt(layers) beyond that -- 32 layers (the Llama-2-7b-dims traces): 0.113."""
+    """Logit tolerance of a replay against the reference's CPU run, beyond 4 fp16 ulps of the value: `base` for the
+    2-12-layer trace models (tensor-parallel replays with their extra roundings included); every decoder layer adds two
+    fp16 roundings of the residual stream, independent between the two runs, so deeper models get base * sqrt(layers / 14).
+    The numbers next to their evidence (MI355X, printed by every session: conftest.pytest_terminal_summary, LOGIT_EXCESS):
+    measured 0.020 at <= 12 layers (tolerance 0.040), 0.028 at 32 layers (B_7b / C_7b: 0.060), 0.036 at 40 layers (D_13b:
+    0.068).  Rounds 2-3 allowed 0.113 at 32 layers -- four times what is observed."""
     layers = meta["target_dims"][2]
-    return base if layers <= 12 else base * (layers / 4.0) ** 0.5
+    return base if layers <= 12 else base * (layers / 14.0) ** 0.5
 
 
 def check_replay(steps, z, meta, logit_tol=None):
@@ -276,6 +283,9 @@ def check_replay(steps, z, meta, logit_tol=None):
             return float((np.abs(np.where(fin, got, 0) - np.where(fin, ref, 0)) - np.abs(np.where(fin, ref, 0)) * 2.0 ** -8).max())
         dd = excess(rec["draft_logits"][internal][:, ::stride], ref_d[internal]) if internal else 0.0
         dt = excess(rec["target_logits"][ok][:, ::stride], ref_t[ok])
+        key = (meta.get("name", "?"), meta["target_dims"][2])
+        prev = LOGIT_EXCESS.get(key, (float("-inf"), float("-inf"), logit_tol))
+        LOGIT_EXCESS[key] = (max(prev[0], dd), max(prev[1], dt), logit_tol)
         assert dd <= logit_tol and dt <= logit_tol, f"step {s}: logits off by {dd:.4f} / {dt:.4f} beyond 4 ulps"
         if rec["accept_len"] == rec["ref_accept_len"] and np.array_equal(rec["valid"], rec["ref_valid"]):
             continue

@@ -1,5 +1,5 @@
-# the 8-step B_7b fixture on the GPU: host-driven replay, whole-step graphs
+# measured logit distance of every committed trace on the GPU (printed by the pytest summary): evidence for the tolerances
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r04/exp9
 mkdir -p $O
-timeout 900 python -m pytest tests/test_e2e_gpu.py tests/test_step_pipeline_gpu.py -m gpu -q -k "B_7b" > $O/tests_b7b.log 2>&1; tail -6 $O/tests_b7b.log | cut -c1-400
+timeout 1200 python -m pytest tests/test_e2e_gpu.py tests/test_baselines_gpu.py -m gpu -q -k "reproduces_reference_tokens or follows_reference" > $O/tests_logit_excess.log 2>&1; grep -A30 "logit distance" $O/tests_logit_excess.log | cut -c1-200; tail -2 $O/tests_logit_excess.log
