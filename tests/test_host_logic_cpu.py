@@ -135,3 +135,30 @@ def test_loop_run_prompts_counts_whole_prompts_and_prefill_steps():
         assert steps >= 2 and toks >= 2 * 12 and 0 < loop.prefill_seconds <= secs + 1.0
     finally:
         ops.set_ops_for_testing(None)
+
+
+def test_collective_fault_word_stops_the_loop():
+    """Engine/xgmi_allreduce.py: a collective kernel whose bounded spin ran out ORs its status bits into a word of pinned
+    host memory; raise_on_fault() -- called by verify() / collect_step() at every step -- turns that into an exception
+    instead of letting the job decode on stale partial sums.  Host logic only: the word is set by hand."""
+    import weakref
+    from sequoia_amd.Engine import xgmi_allreduce as XA
+
+    class Fake(XA.XgmiAllReduce):
+        def __init__(self):                       # no workspace, no device: only the fault word and the registry entry
+            self.rank, self.fault = 3, torch.zeros(16, dtype=torch.int32)
+            XA._LIVE.append(weakref.ref(self))
+
+    ar = Fake()
+    try:
+        XA.raise_on_fault()                       # clean word: nothing happens
+        ar.fault[0] = 1 | 8
+        with pytest.raises(XA.XgmiCollectiveTimeout) as e:
+            XA.raise_on_fault()
+        assert "rank 3" in str(e.value) and "phase 1" in str(e.value) and "'read' flag" in str(e.value)
+        ar.clear_fault()
+        XA.raise_on_fault()
+    finally:
+        XA._LIVE[:] = [r for r in XA._LIVE if r() is not None and r() is not ar]
+    del ar
+    XA.raise_on_fault()                           # dead entries are pruned, not dereferenced
