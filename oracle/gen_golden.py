@@ -142,13 +142,15 @@ def kv_checksum(engine):
 
 def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, prompt_len, max_steps, seed,
              logit_gain=24.0, share_weights=0.0, out_dir=None, seeded=False, share_vocab=0.0, compact=0,
-             branch_scale=1.0, lead=None, top_p=1.0, draft_lm_scale=1.0):
+             branch_scale=1.0, lead=None, top_p=1.0, draft_lm_scale=1.0, lean=False):
     """mode: 'stochastic' (SpecTree), 'greedy' (GreedyTree), 'specinfer' (SpecInferTree: draws with replacement)
     or 'greedys' (GreedySTree: greedy draft tree, target token sampled per node).
     top_p < 1: the nucleus filter of utils.py:65-77 on the target logits (tests/testbed.py:28 defaults to --P 0.9).
     draft_lm_scale (seeded pairs): the correlated draft's lm_head is multiplied by it after `correlate` -- a narrower draft
     normalises its residual stream over fewer dimensions than the target, so its logits come out flatter by a constant
-    factor; the scale puts the two distributions at the same temperature (deeper accepted paths)."""
+    factor; the scale puts the two distributions at the same temperature (deeper accepted paths).
+    lean (the 193- / 256- / 512-node trees): the samplers' input rows are not stored a second time -- level i's inputs are
+    draft_logits_pre[roots[i]] and rand[roots[i]] (Tree/SpecTree.py:103), which the trace holds anyway."""
     RU = R["RU"]
     g = torch.load(growmap_path, weights_only=False)
     n = g["size"]
@@ -289,7 +291,7 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
             dl_pre = tree.draft_logits[:n].numpy().copy()
             arrays[f"{pre}/draft_logits_pre"] = dl_pre[:, ::compact] if compact else dl_pre
             for (lvl, ins, out) in samp_log:
-                if not compact:
+                if not compact and not lean:
                     arrays[f"{pre}/samp{lvl}/logits"] = ins[0]
                     if len(ins) > 1:
                         arrays[f"{pre}/samp{lvl}/rand"] = ins[1]
@@ -353,7 +355,7 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
                 arrays[f"{pre}/residual"] = step_box["last_residual"]
             if mode == "greedys":
                 arrays[f"{pre}/target_token"] = step_box["target_token"]
-            if not compact:
+            if not compact and not lean:
                 arrays[f"{pre}/draft_logits_post"] = tree.draft_logits[:n].numpy().copy()
             arrays[f"{pre}/kv_draft"] = kv_checksum(draft)
             arrays[f"{pre}/kv_target"] = kv_checksum(target)
@@ -373,7 +375,8 @@ def run_case(R, name, growmap_path, draft_dims, target_dims, vocab, M, T, mode, 
                 target_dims=list(target_dims), vocab=vocab, M=M, T=T, mode=mode, prompt_len=prompt_len,
                 seed=seed, logit_gain=logit_gain, share_weights=share_weights, n_tree=int(n),
                 **({"top_p": float(top_p)} if top_p != 1.0 else {}),
-                successors=g["Successors"], torch=torch.__version__, seeded=seeded_meta, compact=int(compact))
+                successors=g["Successors"], torch=torch.__version__, seeded=seeded_meta, compact=int(compact),
+                **({"lean": True} if lean else {}))
     arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     out_dir = out_dir or os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
@@ -624,6 +627,26 @@ def main():
     t70w = (8192, 28672, 2, 64, 8)
     run_case(R, "E_70b_w2", gm("L40_growmaps/64x2-tree.pt"), d7w, t70w, 32000, 384, 0.6, "stochastic", 128, 3, 44,
              logit_gain=0.5, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.003, lead=(4096, 4.0), out_dir=out_dir)
+    # Round 5: the reference's LARGE growmaps (README.md:47,54: M >= #tree + max_target_seq) -- 193 nodes / depth 24
+    # (L40_growmaps/8x24-tree.pt), 256 and 512 nodes (A100-CNN-68m-13b-stochastic-S256 / -S512: up to 116 parents and 32
+    # children per level, 4 / 8 ancestor-bitmask words, a verify forward of 193-512 rows).  Tiny dims at V = 1024 for all
+    # three (+ GreedyTree on the 193-node tree), one V = 32000 compact case on S256 (68m-dims -> 160m-dims).
+    # Seeds: with 200-500 sampled nodes and 3-11 accepted tokens per step a step holds several hundred decisions, and a
+    # trace whose replay is to be token-identical on OTHER arithmetic (fused GEMMs, a GPU) must not carry one that sits on
+    # a rounding boundary.  The seeds below are the ones whose steps all survived 6 host-loop replays with every logit
+    # perturbed by +-0.015 (three times the measured GPU-vs-reference distance); about one seed in four does.
+    big = lambda p: gm(p)
+    run_case(R, "L_8x24", big("L40_growmaps/8x24-tree.pt"), tiny, tiny, 1024, 512, 0.6, "stochastic", 20, 3, 68,
+             logit_gain=8.0, share_weights=0.05, lean=True, out_dir=out_dir)
+    run_case(R, "L_8x24_greedy", big("L40_growmaps/8x24-tree.pt"), tiny, tiny, 1024, 512, 0.6, "greedy", 20, 3, 52,
+             logit_gain=8.0, share_weights=0.05, lean=True, out_dir=out_dir)
+    run_case(R, "L_S256", big("A100_growmaps/68m_13b/growmaps/A100-CNN-68m-13b-stochastic-S256.pt"), tiny, tiny, 1024, 512, 0.6,
+             "stochastic", 24, 3, 65, logit_gain=8.0, share_weights=0.05, lean=True, out_dir=out_dir)
+    run_case(R, "L_S512", big("A100_growmaps/68m_13b/growmaps/A100-CNN-68m-13b-stochastic-S512.pt"), tiny, tiny, 1024, 768, 0.6,
+             "stochastic", 16, 2, 51, logit_gain=8.0, share_weights=0.05, lean=True, out_dir=out_dir)
+    run_case(R, "L_S256_v32k", big("A100_growmaps/68m_13b/growmaps/A100-CNN-68m-13b-stochastic-S256.pt"), d68, t160, 32000, 512, 0.6,
+             "stochastic", 32, 3, 56, logit_gain=10.0, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.005,
+             out_dir=out_dir)
     # the acceptance-rate probes of tests/test_accept.py (fp32 noise, p >= r q in fp32; top-k children / argmax)
     run_probe_case(R, "P_spectest", "spectest", tiny, 1024, 128, 0.6, 8, 16, 12, 31, noise=0.6, out_dir=out_dir)
     run_probe_case(R, "Q_greedytest", "greedytest", tiny, 1024, 128, 0.6, 8, 16, 12, 32, noise=0.6, out_dir=out_dir)

@@ -70,6 +70,13 @@ WIDTH_TRACES = ["D_13b_w4", "E_70b_w2"]
 # configuration D at FULL DEPTH: Sheared-LLaMA-1.3B dims (24 layers) -> Llama-2-13b dims (40 layers), 26 GB of seeded weights
 # (two to three minutes of CPU generation on the GPU box, shared by the tests of one process)
 DEPTH_TRACES = ["D_13b"]
+# Round 5: the reference's LARGE growmaps -- 193 nodes / depth 24 (L40_growmaps/8x24-tree.pt, SpecTree and GreedyTree), 256 and
+# 512 nodes (A100-CNN-68m-13b-stochastic-S256 / -S512: 4 / 8 ancestor-bitmask words, up to 116 parents x 32 children per
+# level, verify forwards of 193-512 rows).  "lean" traces: the samplers' inputs are draft_logits_pre[roots[i]], rand[roots[i]]
+LARGE_STOCHASTIC = ["L_8x24", "L_S256", "L_S512"]
+LARGE_GREEDY = ["L_8x24_greedy"]
+LARGE_TRACES = LARGE_STOCHASTIC + LARGE_GREEDY
+LARGE_COMPACT = ["L_S256_v32k"]          # S256 at V = 32000 (68m-dims -> 160m-dims, seeded weights, compact logits)
 BASELINE_TRACES = ["F_specinfer", "G_greedys"]        # the paper's comparison baselines (SpecInferTree, GreedySTree)
 
 

@@ -11,16 +11,21 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import COMPACT_TRACES, DEPTH_TRACES, HEADLINE_TRACES, TOPP_TRACES, TRACE_NAMES, WIDTH_TRACES, load_trace
+from conftest import (COMPACT_TRACES, DEPTH_TRACES, HEADLINE_TRACES, LARGE_COMPACT, LARGE_TRACES, TOPP_TRACES, TRACE_NAMES, WIDTH_TRACES,
+                      load_trace)
 from helpers import assert_replay_complete, build_engines, check_replay, make_tree, replay_trace
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("name", TRACE_NAMES + COMPACT_TRACES + TOPP_TRACES + HEADLINE_TRACES + WIDTH_TRACES + DEPTH_TRACES)
+@pytest.mark.parametrize("name", TRACE_NAMES + COMPACT_TRACES + TOPP_TRACES + HEADLINE_TRACES + WIDTH_TRACES + DEPTH_TRACES + LARGE_TRACES
+                         + LARGE_COMPACT)
 def test_gpu_loop_reproduces_reference_tokens(name):
-    """All steps of every trace (configs A-E shapes, the demo tree, the V = 32000 trace, the same pair under the harness's
+    """(round 5: + the reference's 193- / 256- / 512-node growmaps -- L_*: 4 and 8 ancestor-bitmask words in the attention
+    kernel, the verifier at n = 512, sampler levels of up to 116 rows x 32 children, verify forwards of 193-512 rows, which
+    leave the <= 144-row tall-skinny path for the hipBLASLt forward)
+    All steps of every trace (configs A-E shapes, the demo tree, the V = 32000 trace, the same pair under the harness's
     default nucleus filter top_p = 0.9 -- sq_top_p_filter_f16 in front of the verifier --, and the two traces at the
     headline model dims: 68m -> Llama-2-7b architectures, SpecTree 128-node growmap and GreedyTree 8x8).  Logits agree within
     tolerance in every compared step (asserted inside check_replay); the committed tokens are identical in every

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, STOCHASTIC_TRACES, load_trace
+from conftest import GOLDEN, LARGE_GREEDY, LARGE_STOCHASTIC, STOCHASTIC_TRACES, load_trace
 from helpers import assert_top_p_equal_up_to_ties, cdf_interval_distance, note_escape, split_margin
 from oracle import ops_np as O
 
@@ -58,7 +58,7 @@ def random_tree(rng, n, max_children=6):
 
 
 # ---- a1 -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,gt", [(2, 5), (65, 17), (128, 128), (300, 40)])
+@pytest.mark.parametrize("n,gt", [(2, 5), (65, 17), (128, 128), (300, 40), (512, 256)])
 def test_tree_mask_dense(ops, n, gt):
     rng = np.random.RandomState(n)
     succ = random_tree(rng, n)
@@ -164,6 +164,12 @@ def _attn_case(rng, H, Hkv, D, M, gt, n, q_slot0, q_len):
     (8, 1, 128, 1024, 700, 129, 699, 129),  # config E shard: 8 q-heads on 1 KV head, long prefix
     (40, 40, 128, 384, 140, 64, 139, 64),  # config D target verify: Llama-2-13b head count (40 = 5 x 8), 64-node tree
     (16, 16, 128, 384, 140, 64, 152, 20),  # config D draft level (Sheared-LLaMA-1.3B: 16 heads of D = 128), level 3
+    # round 5: the reference's large growmaps (SQ_MAX_TREE = 512: 4 and 8 bitmask words)
+    (12, 12, 64, 768, 200, 512, 324, 116),  # S512 draft level 3: 116 new nodes, 8 words, D = 64
+    (4, 4, 128, 768, 129, 512, 128, 512),   # S512 target verify: 512 query rows, kv_len 640, 8 words
+    (8, 2, 128, 512, 100, 256, 99, 256),    # S256 target verify, GQA 4:1, 4 words
+    (12, 12, 64, 512, 40, 193, 0, 232),     # 8x24 (193 nodes, depth 24, 4 words): first verify = prefix + tree
+    (8, 8, 128, 1024, 512, 300, 511, 300),  # 5 words, long prefix
 ])
 def test_tree_attention_vs_fp32_reference(ops, H, Hkv, D, M, gt, n, q_slot0, q_len):
     rng = np.random.RandomState(H * 7 + q_len)
@@ -195,7 +201,9 @@ def _check_topk(got, want, keys):
 
 
 @pytest.mark.parametrize("V,n_rows,k,gain", [(1024, 5, 7, 3.0), (32000, 19, 13, 4.0), (32000, 1, 19, 2.0),
-                                             (32000, 3, 64, 6.0), (4096, 8, 1, 1.0)])
+                                             (32000, 3, 64, 6.0), (4096, 8, 1, 1.0),
+                                             (32000, 116, 32, 4.0),      # S512 level 3: 116 parents; level 0 / 1: k = 32
+                                             (1024, 116, 32, 3.0), (32000, 93, 21, 5.0)])
 def test_sample_wor(ops, V, n_rows, k, gain):
     rng = np.random.RandomState(V + k)
     R = n_rows + 3
@@ -270,7 +278,7 @@ def _run_verify_stochastic(ops, target, draft, tokens, r16, succ, gt, T, u24):
     return res.cpu().numpy(), d_tokens.cpu().numpy(), d_draft.cpu().numpy()
 
 
-@pytest.mark.parametrize("name", STOCHASTIC_TRACES)
+@pytest.mark.parametrize("name", STOCHASTIC_TRACES + LARGE_STOCHASTIC)
 def test_verify_stochastic_on_reference_traces(ops, name):
     """Inputs recorded from the reference run; the kernel must reproduce the reference's accepted
     tokens, bonus and -65504 writes in EVERY step (committed fixtures are fail-closed: margin excuses exist only for
@@ -304,7 +312,7 @@ def test_verify_stochastic_on_reference_traces(ops, name):
             assert tok_after[a] == want["bonus"]
 
 
-@pytest.mark.parametrize("V,n,seed", [(1024, 40, 0), (32000, 128, 1), (32000, 6, 2)])
+@pytest.mark.parametrize("V,n,seed", [(1024, 40, 0), (32000, 128, 1), (32000, 6, 2), (1024, 512, 3), (32000, 512, 4), (4096, 256, 5)])
 def test_verify_stochastic_random(ops, V, n, seed):
     rng = np.random.RandomState(seed)
     succ = random_tree(rng, n, max_children=8)
@@ -373,8 +381,9 @@ def test_verify_stochastic_nan_and_eos(ops):
     assert res[3] == 1 and res[4] == 1 and res[0] == want["accept_len"] and res[2] == -1
 
 
-def test_verify_greedy(ops):
-    z, meta = load_trace("C_greedy8x8")
+@pytest.mark.parametrize("name", ["C_greedy8x8"] + LARGE_GREEDY)
+def test_verify_greedy(ops, name):
+    z, meta = load_trace(name)
     succ = meta["successors"]
     n = len(succ)
     off, ids = csr(succ)

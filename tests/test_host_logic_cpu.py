@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TOPP_TRACES, TRACE_NAMES
+from conftest import LARGE_TRACES, TOPP_TRACES, TRACE_NAMES
 from helpers import check_replay, replay_trace
 
 
@@ -22,7 +22,8 @@ def oracle_ops():
     ops.set_ops_for_testing(None)
 
 
-@pytest.mark.parametrize("name", TRACE_NAMES + TOPP_TRACES)      # (+ V = 32000 under the harness's default top_p = 0.9: 30 s)
+# (+ V = 32000 under the harness's default top_p = 0.9: 30 s; + the reference's 193- / 256- / 512-node growmaps)
+@pytest.mark.parametrize("name", TRACE_NAMES + TOPP_TRACES + LARGE_TRACES)
 def test_native_loop_reproduces_reference_trace(oracle_ops, name):
     steps, tree, draft, target, z, meta = replay_trace(name, "cpu")
     assert len(steps) == int(z["n_steps"])

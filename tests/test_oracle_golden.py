@@ -9,13 +9,14 @@ bit-exact for token / index / integer results, and within one fp16 ulp for proba
 import numpy as np
 import pytest
 
-from conftest import COMPACT_TRACES, GOLDEN, STOCHASTIC_TRACES, TOPP_TRACES, TRACE_NAMES, load_trace
+from conftest import (COMPACT_TRACES, GOLDEN, LARGE_COMPACT, LARGE_GREEDY, LARGE_STOCHASTIC, LARGE_TRACES, STOCHASTIC_TRACES,
+                      TOPP_TRACES, TRACE_NAMES, load_trace)
 
-COMPACT_STOCHASTIC = COMPACT_TRACES + TOPP_TRACES + ["B_7b", "D_13b_w4", "E_70b_w2", "D_13b"]        # + the headline-dims SpecTree trace (68m -> 7B dims)
+COMPACT_STOCHASTIC = COMPACT_TRACES + TOPP_TRACES + ["B_7b", "D_13b_w4", "E_70b_w2", "D_13b"] + LARGE_COMPACT        # + the headline-dims SpecTree trace (68m -> 7B dims)
 from oracle import ops_np as O
 
 
-@pytest.mark.parametrize("name", TRACE_NAMES)
+@pytest.mark.parametrize("name", TRACE_NAMES + LARGE_TRACES)
 def test_bitmask_equals_growmap_mask(name):
     z, meta = load_trace(name)
     succ = meta["successors"]
@@ -30,21 +31,33 @@ def test_bitmask_equals_growmap_mask(name):
     assert np.array_equal(dense, win)
 
 
-@pytest.mark.parametrize("name", TRACE_NAMES)
+def sampler_inputs(z, meta, s, lvl, roots):
+    """(logits, rand) the reference's sampler of level lvl saw in step s: stored, or -- lean traces -- the rows
+    draft_logits_pre[roots[lvl]] / rand[roots[lvl]] (Tree/SpecTree.py:103: the rows are final once their level ran)."""
+    if f"step{s}/samp{lvl}/logits" in z:
+        return z[f"step{s}/samp{lvl}/logits"], (z[f"step{s}/samp{lvl}/rand"] if meta["mode"] == "stochastic" else None)
+    assert meta.get("lean")
+    idx = roots[lvl]
+    return z[f"step{s}/draft_logits_pre"][idx], (z["rand"][idx] if meta["mode"] == "stochastic" else None)
+
+
+@pytest.mark.parametrize("name", TRACE_NAMES + LARGE_TRACES)
 def test_sampler_matches_reference(name):
+    from sequoia_amd.growmap import GrowMap
     z, meta = load_trace(name)
     succ = meta["successors"]
+    roots = GrowMap.from_successors(succ).roots
     n_steps = int(z["n_steps"])
     checked = 0
     for s in range(n_steps):
         lvl = 0
-        while f"step{s}/samp{lvl}/logits" in z:
-            logits = z[f"step{s}/samp{lvl}/logits"]
+        while f"step{s}/samp{lvl}/out" in z:
+            logits, rnd = sampler_inputs(z, meta, s, lvl, roots)
             want = z[f"step{s}/samp{lvl}/out"]
             k = want.shape[0] // logits.shape[0]
             if meta["mode"] == "stochastic":
-                got = O.sample_wor(logits, z[f"step{s}/samp{lvl}/rand"], k, meta["T"])
-                keys = O.sample_keys(logits, z[f"step{s}/samp{lvl}/rand"], meta["T"])
+                got = O.sample_wor(logits, rnd, k, meta["T"])
+                keys = O.sample_keys(logits, rnd, meta["T"])
             else:
                 got = O.topk_ids(logits, k)
                 keys = logits
@@ -91,7 +104,7 @@ def test_sampler_rows_full_vocab():
         assert (a != b).mean() < 0.01
 
 
-@pytest.mark.parametrize("name", STOCHASTIC_TRACES)
+@pytest.mark.parametrize("name", STOCHASTIC_TRACES + LARGE_STOCHASTIC)
 def test_verify_stochastic_matches_reference(name):
     z, meta = load_trace(name)
     succ = meta["successors"]
@@ -110,12 +123,13 @@ def test_verify_stochastic_matches_reference(name):
         valid = z[f"step{s}/valid_tokens"]
         assert np.array_equal(tokens[:valid.shape[0]], valid), f"{name} step {s}"
         # the -65504 writes into the draft rows of the walked nodes (Tree/SpecTree.py:156)
-        post = z[f"step{s}/draft_logits_post"]
-        # (row 0 is overwritten by prepare_for_next_iter's 1-token draft forward, :279)
-        walked = [sl - (gt - 1) for sl in res["slots"]]
-        for t in walked:
-            if len(succ[t]):
-                assert np.array_equal(draft[t], post[t]), f"{name} step {s} node {t}"
+        if f"step{s}/draft_logits_post" in z:      # (lean traces keep the rows once)
+            post = z[f"step{s}/draft_logits_post"]
+            # (row 0 is overwritten by prepare_for_next_iter's 1-token draft forward, :279)
+            walked = [sl - (gt - 1) for sl in res["slots"]]
+            for t in walked:
+                if len(succ[t]):
+                    assert np.array_equal(draft[t], post[t]), f"{name} step {s} node {t}"
         if f"step{s}/residual" in z:
             a16 = res["final_p"].view(np.int16).astype(np.int32)
             b16 = z[f"step{s}/residual"].view(np.int16).astype(np.int32)
@@ -228,8 +242,9 @@ def test_verify_greedy_matches_reference_headline_dims():
     assert accepted >= 1
 
 
-def test_verify_greedy_matches_reference():
-    z, meta = load_trace("C_greedy8x8")
+@pytest.mark.parametrize("name", ["C_greedy8x8"] + LARGE_GREEDY)
+def test_verify_greedy_matches_reference(name):
+    z, meta = load_trace(name)
     succ = meta["successors"]
     for s in range(int(z["n_steps"])):
         gt = int(z[f"step{s}/gt"])

@@ -1,0 +1,85 @@
+# GPU-box stages of round 5 (run through gpurun; everything lands under gpurun_out/r05/):
+#   bash tools/gpu_r05.sh <stage> [<stage> ...]
+#   large     the round's new parity surface: the reference's 193- / 256- / 512-node growmaps (kernel level, host-driven loop, whole-step graphs)
+#   kernels   tests/test_hip_kernels.py (every C-ABI kernel against the oracle)
+#   tests     the whole GPU suite + smoke()
+#   pmc_ns    PMC passes of the north-star kernels (samplers, verifier): FETCH_SIZE | WRITE_SIZE | SQ group, separate rocprofv3 runs
+#   pmc_l2    L2 / TA / SQ counters of the 7B projections at the shipped 128-row plans (tools/ts_bench)
+#   bench     the driver's command line
+#   benchfull the default line (200 steps, other_configs, cpu_baseline)
+#   loop      rocprofv3 --kernel-trace --stats of the loop alone
+#   exp:<name>=<env assignments>   bench.py --steps 60 under the given environment (comma-separated VAR=VALUE), e.g. exp:ov0=SEQUOIA_OVERLAP_LAST_LEVEL=0
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/r05
+mkdir -p $O
+export TMPDIR=/tmp
+line() { python - "$1" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d.get("roofline") or {}
+    print(sys.argv[1].split("/")[-1], round(d["value"], 1), d["unit"], round(d["ms_per_step"], 3), "ms/step", d.get("mean_accepted_len"),
+          "steady", d.get("value_steady"), "roof", r.get("kernel"), r.get("frac") and round(r["frac"], 3), "step_frac", (d.get("step_roofline") or {}).get("frac"))
+    for c, o in (d.get("other_configs") or {}).items():
+        print("   config", c, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in o.items() if k in ("value", "ms_per_step", "mean_accepted_len", "error", "weight_build_s")},
+              "roof", (o.get("roofline") or {}).get("kernel"), (o.get("roofline") or {}).get("frac"), "step_frac", (o.get("step_roofline") or {}).get("frac"))
+    k = d.get("kernels") or {}
+    print("   kernels us/step:", {n: round(v["per_step_us"], 1) for n, v in k.items()})
+except Exception as e:
+    print(sys.argv[1], "failed:", e)
+PY
+}
+pmc() {   # pmc <tag> <counters...> -- <command...>
+  tag=$1; shift; ctr=""; while [ "$1" != "--" ]; do ctr="$ctr $1"; shift; done; shift
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc/$tag -o r -- "$@" > $O/pmc/$tag.log 2>&1)
+}
+for stage in "$@"; do
+  echo "=== $stage"
+  case $stage in
+  large)
+    timeout 1500 python -m pytest tests/test_hip_kernels.py tests/test_e2e_gpu.py tests/test_step_pipeline_gpu.py -m gpu -q -k "L_ or 512 or 116 or 93 or 300 or 193 or 256" > $O/tests_large.log 2>&1
+    grep -n "passed\|failed\|rror" $O/tests_large.log | tail -12 ;;
+  kernels)
+    timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q > $O/tests_kernels.log 2>&1; tail -3 $O/tests_kernels.log ;;
+  tests)
+    timeout 2400 python -m pytest tests -m gpu -x -q > $O/tests_gpu.log 2>&1; grep -n "passed\|failed\|error" $O/tests_gpu.log | tail -3
+    python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 ;;
+  pmc_ns)
+    mkdir -p $O/pmc
+    for what in samp verify; do
+      pmc ns_${what}_FETCH FETCH_SIZE -- python $GRAFT_REPO_ROOT/tools/kbench.py $what
+      pmc ns_${what}_WRITE WRITE_SIZE -- python $GRAFT_REPO_ROOT/tools/kbench.py $what
+      pmc ns_${what}_SQ SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python $GRAFT_REPO_ROOT/tools/kbench.py $what
+    done
+    args=""; for d in $O/pmc/ns_*/; do db=$(find $d -name "*results.db" | head -1); [ -n "$db" ] && args="$args $(basename $d)=$db"; done
+    python tools/pmc_summary.py $O/pmc_northstar_raw.json $args > /dev/null; find $O/pmc -name "*.db" -delete
+    python tools/pmc_r05_summary.py northstar $O/pmc_northstar_raw.json $O/pmc_northstar.json ;;
+  pmc_l2)
+    mkdir -p $O/pmc
+    for spec in "qkv:qkv:128:2" "o:o+res:64:4" "gate_up:gate_up+silu:230:1" "down:down+res:64:4"; do
+      IFS=: read tag shape tiles splits <<< "$spec"
+      export TS_ARCH=7b TS_ONLY="$shape" TS_TILES=$tiles TS_SPLITS=$splits
+      pmc l2_${tag}_TCC TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_BUSY_avr GRBM_GUI_ACTIVE -- $GRAFT_REPO_ROOT/tools/ts_bench 128
+      pmc l2_${tag}_TCP TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum -- $GRAFT_REPO_ROOT/tools/ts_bench 128
+      pmc l2_${tag}_SQ SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU -- $GRAFT_REPO_ROOT/tools/ts_bench 128
+      unset TS_ARCH TS_ONLY TS_TILES TS_SPLITS
+    done
+    args=""; for d in $O/pmc/l2_*/; do db=$(find $d -name "*results.db" | head -1); [ -n "$db" ] && args="$args $(basename $d)=$db"; done
+    python tools/pmc_summary.py $O/pmc_l2_raw.json $args > /dev/null; find $O/pmc -name "*.db" -delete
+    python tools/pmc_r05_summary.py l2 $O/pmc_l2_raw.json $O/pmc_l2.json ;;
+  bench)
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; line $O/bench_driver_cmd.json ;;
+  benchfull)
+    timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; line $O/bench_default.json ;;
+  loop)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_loop -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 120 --warmup 8 --no-kernel-rooflines --no-cpu-baseline --no-tuned-growmap --no-autoregressive --no-other-configs --no-reference-metric > $O/prof_loop.log 2>&1)
+    python tools/rocprof_summary.py $(find $O/prof_loop -name "*results.db" | head -1) 40 > $O/kernel_stats_loop_only.md; find $O/prof_loop -name "*.db" -delete
+    head -24 $O/kernel_stats_loop_only.md ;;
+  exp:*)
+    spec=${stage#exp:}; name=${spec%%=*}; envs=${spec#*=}
+    ( IFS=,; for kv in $envs; do export "$kv"; done; unset IFS
+      timeout 600 python bench.py --steps 60 --warmup 8 ${BENCH_ARGS:---no-kernel-rooflines --no-cpu-baseline --no-tuned-growmap --no-autoregressive --no-other-configs --no-reference-metric} > $O/exp_$name.json 2> $O/exp_$name.err )
+    line $O/exp_$name.json ;;
+  *) echo "unknown stage $stage" ;;
+  esac
+done
