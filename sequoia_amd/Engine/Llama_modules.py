@@ -44,6 +44,10 @@ class TreeContext:
     # device-driven step (Tree/step_graph.py): the arguments of ops.stage_tree_inputs for this forward's static input buffers;
     # a forward on the tall-skinny path stages its inputs inside its first launch (ops.embed_stage_rmsnorm)
     stage: tuple | None = None
+    # False: the caller needs this forward's KV rows only, not its logits -- the draft forward over the LAST tree level
+    # (its nodes are leaves: no child is ever sampled from their rows, Tree/SpecTree.py:103).  The tall-skinny forward
+    # then stops after the last layer's RoPE + KV write (Engine/ts_linear.py::forward_ts) and returns None.
+    need_logits: bool = True
 
 
 @dataclass
@@ -57,11 +61,11 @@ class LayerWeights:
 
 
 def attention_core(qkv, layer_idx: int, dims, kv_cache, cos, sin, position_ids, storage_ids, dense_mask,
-                   tree: TreeContext | None, out_frag: bool = False, qkv_slab=None):
+                   tree: TreeContext | None, out_frag: bool = False, qkv_slab=None, kv_only: bool = False):
     """qkv: [q, (H + 2 H_kv) D] packed projections -- or qkv_slab = (fp32 slab, splits, q_len): the split-K partials of the
     tall-skinny projection, summed by the RoPE kernel.  RoPE + KV slot write + tree-batched attention;
     returns the attention output [q, H D] (the o_proj input), or with out_frag its fragment-major image
-    (the operand layout of the tall-skinny o_proj, Engine/ts_linear.py)."""
+    (the operand layout of the tall-skinny o_proj, Engine/ts_linear.py).  kv_only: RoPE + KV slot write alone (returns None)."""
     ops = get_ops()
     q_len = qkv.shape[0] if qkv_slab is None else qkv_slab[2]
     n_heads, h_kv, d = dims.local_heads, dims.local_kv_heads, dims.head_dim
@@ -76,6 +80,8 @@ def attention_core(qkv, layer_idx: int, dims, kv_cache, cos, sin, position_ids, 
                                 position_ids, storage_ids, n_heads, h_kv, d)
     else:
         ops.rope_kv_write(qkv, q_rot, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d)
+    if kv_only:
+        return None
     if tree is not None:
         ops.tree_attention(q_rot, k_layer, v_layer, attn, tree.kv_len, scale, q_slot0=tree.q_slot0, gt=tree.gt,
                            n_tree=tree.n_tree, bitmask=tree.bitmask, ctx=tree.ctx, **frag_kw)

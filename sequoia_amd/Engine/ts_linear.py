@@ -399,7 +399,9 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
     projections (o_proj, down_proj) is reduced across ranks before the residual add; the vocabulary-parallel logits
     are gathered at the end (model.gather_logits_fn)."""
     stage = tree.stage if tree is not None else None
-    if small_fused_ok(model, ts, q_len):
+    # the caller wants the KV rows only (draft forward over the last tree level): stop after the last layer's KV write
+    kv_only = tree is not None and not tree.need_logits
+    if small_fused_ok(model, ts, q_len) and not kv_only:
         if stage is not None:
             get_ops().stage_tree_inputs(*stage)
         return forward_small_fused(model, ts, ids, q_len, pos, storage_ids, dense, tree, kv_cache)
@@ -486,12 +488,16 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
         else:
             h = reduce_norm(pending, lw.ln1, plan["qkv"] is not None)
         qkv = project("qkv", li, h)
+        stop = kv_only and li == len(W.layers) - 1
         if qkv[0] == "slab":
             attn = attention_core(None, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
-                                  out_frag=plan["o"] is not None, qkv_slab=(slab, qkv[1], q_len))
+                                  out_frag=plan["o"] is not None, qkv_slab=(slab, qkv[1], q_len), kv_only=stop)
         else:
             attn = attention_core(qkv[1], li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
-                                  out_frag=plan["o"] is not None)
+                                  out_frag=plan["o"] is not None, kv_only=stop)
+        if stop:                 # nothing downstream of the last layer's K / V rows is needed
+            kv_cache.note_written(q_len)
+            return None
         h = reduce_norm(project("o", li, attn), lw.ln2, plan["gate_up"] is not None)
         down_ts = plan["down"] is not None
         act = torch.empty(fs(q_len, inter) if down_ts else (q_len, inter), dtype=dt, device=dev)

@@ -16,6 +16,7 @@ import os
 import torch
 
 from ..Engine.Llama_modules import TreeContext
+from ..Engine.ts_linear import MAX_ROWS as TS_MAX_ROWS
 from ..native import (SQ_RES_N_TREE, SQ_RESULT_INTS, SQ_RESULT_RING, SQ_STEP_ACTIVE, SQ_STEP_GT, SQ_STEP_INTS,
                       SQ_VERIFY_GATHER_FIRST)
 from ..ops import get_ops
@@ -25,6 +26,14 @@ N_BONUS = 1024
 # "1": a forward on the tall-skinny path stages its own inputs in its first launch (sq_embed_stage_rmsnorm_f16) -- 7 launches per
 # step fewer; "0": sq_stage_tree_inputs in front of every forward
 FUSE_STAGE = os.environ.get("SEQUOIA_FUSE_STAGE", "1") == "1"
+# "1": the draft forward over the LAST tree level leaves the step's critical path.  Its nodes are leaves -- no child is ever
+# sampled from their draft rows (Tree/SpecTree.py:103) -- so the step needs only their KV rows (a leaf can be accepted and
+# then belongs to the next step's context), and needs them only at the KV compaction AFTER the verification.  The forward
+# therefore (a) stops after its last layer's RoPE + KV write (no attention / o_proj / MLP of the last layer, no final norm,
+# no lm_head, no row statistics: TreeContext.need_logits = False) and (b) is captured on a forked stream, concurrent with
+# the target's verify forward, joined before the verifier runs.  Committed tokens are identical by construction (the draft
+# rows of leaves are never read); "0" restores the serial form.
+OVERLAP_LAST_LEVEL = os.environ.get("SEQUOIA_OVERLAP_LAST_LEVEL", "1") == "1"
 
 
 class _Fwd:
@@ -101,7 +110,12 @@ class StepState:
         gt_dev = self.step[SQ_STEP_GT:SQ_STEP_GT + 1]
         depth = g["depth32"]
         dm, tm = self.draft.engine, self.target.engine
-        for lv, f in zip(g["levels"], self.fwd_levels):
+        n_levels = len(g["levels"])
+        # (a sharded draft runs collectives: its forward stays on the step's one stream, in the ranks' common order)
+        overlap = (OVERLAP_LAST_LEVEL and self.cuda and getattr(dm.model, "ts", None) is not None
+                   and getattr(dm.model, "reduce_fn", None) is None)
+        side = None
+        for li, (lv, f) in enumerate(zip(g["levels"], self.fwd_levels)):
             first = lv["first_child"]
             out = self.tokens[first - 1:]                 # + gt on the device: tokens[gt + first - 1 + out_off[r] + s]
             if self.stochastic:
@@ -110,6 +124,20 @@ class StepState:
             else:
                 ops.topk(self.draft_logits, lv["row_ids"], lv["k"], out, branch=lv["branch"], out_off=lv["out_off"],
                          out_base=gt_dev)
+            if overlap and li == n_levels - 1 and lv["total"] <= TS_MAX_ROWS:
+                # leaves: KV rows only, off the critical path.  The inputs are staged on the step's stream (the fork below
+                # orders the side stream behind them; the walker that rewrites `tokens` / the step block runs after the join)
+                f.tree.stage = None
+                f.tree.need_logits = False
+                self.ops.stage_tree_inputs(f.ids, f.pos, f.sto, f.ctx, self.tokens, g["depth32"], self.n, first - 1,
+                                           first - 1 + lv["total"], self.step, False)
+                main = torch.cuda.current_stream()
+                side = self._side_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None, tree=f.tree)
+                continue
+            f.tree.need_logits = True
             self._stage(f, first - 1, first - 1 + lv["total"])
             logits = dm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None, tree=f.tree)
             self._adopt_rows(logits[0], first, lv["total"])
@@ -118,6 +146,8 @@ class StepState:
         target_logits = tm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None,
                                      tree=f.tree)[0]
         self.target_logits = target_logits
+        if side is not None:                                   # join: the leaves' draft KV rows are in place
+            torch.cuda.current_stream().wait_stream(side)
         flags = SQ_VERIFY_GATHER_FIRST if self.commit_order == "lossless" else 0
         if self.stochastic:
             if self.top_p < 1.0:
@@ -135,6 +165,11 @@ class StepState:
         self._stage(f, -1, 0, advance=True)
         logits = dm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None, tree=f.tree)
         self._adopt_rows(logits[0], 0, 1)
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _stage(self, f, rel_slot0, rel_kv_len, advance=False):
         """Inputs of the forward that follows: handed to the model through the forward's TreeContext -- on the tall-skinny

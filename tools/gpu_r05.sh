@@ -30,8 +30,8 @@ except Exception as e:
 PY
 }
 pmc() {   # pmc <tag> <counters...> -- <command...>
-  tag=$1; shift; ctr=""; while [ "$1" != "--" ]; do ctr="$ctr $1"; shift; done; shift
-  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc/$tag -o r -- "$@" > $O/pmc/$tag.log 2>&1)
+  local ptag=$1; shift; local ctr=""; while [ "$1" != "--" ]; do ctr="$ctr $1"; shift; done; shift
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc/$ptag -o r -- "$@" > $O/pmc/$ptag.log 2>&1)
 }
 for stage in "$@"; do
   echo "=== $stage"
