@@ -250,13 +250,32 @@ def step_weight_bytes(loop, gm):
     return dict(target=t, draft=d, draft_forwards=n_draft_forwards, total=t + d * n_draft_forwards)
 
 
+def tp_bytes_per_rank(wb):
+    """Weight bytes one speculation step streams PER RANK at TP = 1 / 2 / 4 / 8 for the two draft placements (the choice
+    harness.build leaves to SEQUOIA_TP_DRAFT: VERDICT r04 weak #10 -- decide it from these bytes and the first real all-reduce
+    latencies, not from ranks time-slicing one GPU).  Target: column- / row-parallel shards + the vocabulary-parallel lm_head
+    = target / W.  Draft replicated: the whole draft x (tree levels + the next-root forward) on every rank; sharded: / W, at
+    the price of 2 all-reduces per draft layer and forward."""
+    out = {}
+    for w in (1, 2, 4, 8):
+        t = wb["target"] / w
+        rep, shd = wb["draft"] * wb["draft_forwards"], wb["draft"] * wb["draft_forwards"] / w
+        out[f"tp{w}"] = dict(target_GB=round(t / 1e9, 2), draft_replicated_GB=round(rep / 1e9, 2), draft_sharded_GB=round(shd / 1e9, 2),
+                             step_GB_replicated_draft=round((t + rep) / 1e9, 2), step_GB_sharded_draft=round((t + shd) / 1e9, 2),
+                             ms_at_6p3TBps_replicated=round((t + rep) / 6.3e12 * 1e3, 2), ms_at_6p3TBps_sharded=round((t + shd) / 6.3e12 * 1e3, 2))
+    return out
+
+
 def run_other_config(name, args, device, prompts, engines=None, steps=20, warmup=5):
-    """Configs C / D after the headline (VERDICT r03 #3c): the same device-driven loop, `steps` timed steps, their own
-    roofline object (dominant kernel by time per step, HIP-event timing on the launch stream)."""
+    """Configs C / D / E after the headline (VERDICT r03 #3c, r04 #5): the same device-driven loop, `steps` timed steps
+    beginning with a fresh prompt like the headline window, their own roofline object (dominant kernel by time per step,
+    HIP-event timing on the launch stream).  E = the 70B target on ONE GPU (TP = 1: 138 GB of fragment-major weights, the
+    only hardware anchor the tensor-parallel configuration has while no multi-GPU node is available to the driver)."""
     cfg = dict(MODELS[name])
     t0 = time.perf_counter()
     if engines is None:
         draft, target, gm = build(cfg, device, args.pair)
+        torch.cuda.synchronize()
     else:
         from sequoia_amd.growmap import GrowMap
         draft, target = engines
@@ -265,11 +284,15 @@ def run_other_config(name, args, device, prompts, engines=None, steps=20, warmup
     torch.manual_seed(17)
     loop = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs,
                 pipelined=not args.sync_loop and not args.no_graphs)
+    weight_build_s = time.perf_counter() - t0 if engines is None else None
     loop.run_steps(warmup)
+    if not args.steady_window:
+        loop.start_fresh_prompt()
     torch.cuda.synchronize()
-    p0 = loop.prefill_steps
+    p0, ps0, pt0 = loop.prefill_steps, loop.prefill_seconds, loop.prefill_tokens
     secs, new_tok, steps_done = loop.run_steps(steps)
     torch.cuda.synchronize()
+    pf_n, pf_s, pf_t = loop.prefill_steps - p0, loop.prefill_seconds - ps0, loop.prefill_tokens - pt0
     kr = kernel_rooflines(cfg, loop, device)
     per_step = {k: v["seconds"] * v["launches_per_step"] if (k == "tree_attention_target" or k.startswith("linear_ts_")) else v["seconds"]
                 for k, v in kr.items()}
@@ -278,12 +301,18 @@ def run_other_config(name, args, device, prompts, engines=None, steps=20, warmup
     wb = step_weight_bytes(loop, gm)
     out = dict(workload=f"config {name}: {cfg['draft']} -> {cfg['target']} architectures, growmap {cfg['growmap']} ({gm.size}-node tree)",
                value=new_tok / secs, unit="tokens/s", ms_per_step=secs / steps_done * 1e3, steps=steps_done, warmup=warmup,
-               mean_accepted_len=new_tok / steps_done, prefill_steps_in_timed_region=loop.prefill_steps - p0,
+               mean_accepted_len=new_tok / steps_done, prefill_steps_in_timed_region=pf_n,
+               prefill_step_ms_in_timed_region=(pf_s / pf_n * 1e3) if pf_n else None,
+               value_steady=(new_tok - pf_t) / max(secs - pf_s, 1e-9), steady_ms_per_step=(secs - pf_s) / max(steps_done - pf_n, 1) * 1e3,
+               weight_build_s=None if weight_build_s is None else round(weight_build_s, 1),
                roofline=dict(bound="hbm", kernel=dom, achieved=d["bytes"] / d["seconds"] / 1e9, peak=8000.0, unit="GB/s",
                              frac=d["bytes"] / d["seconds"] / 1e9 / 8000.0, avg_launch_us=d["seconds"] * 1e6,
                              algorithmic_bytes_per_launch=d["bytes"], time_per_step_us=per_step[dom] * 1e6, plan=d.get("plan"),
                              traffic=None),
-               step_roofline=dict(weight_bytes=wb["total"], frac=wb["total"] / (secs / steps_done) / 8e12),
+               step_roofline=dict(weight_bytes=wb["total"], frac=wb["total"] / ((secs - pf_s) / max(steps_done - pf_n, 1)) / 8e12,
+                                  note="weight bytes of one step over steady_ms_per_step"),
+               **(dict(parallelism="tp1 (the 70B target on one GPU, fragment-major weights only)", tp_bytes_per_rank=tp_bytes_per_rank(wb))
+                  if cfg.get("tp") else {}),
                kernels={k: dict(avg_us=round(v["seconds"] * 1e6, 2), per_step_us=round(per_step[k] * 1e6, 1),
                                 frac=round(v["bytes"] / v["seconds"] / 8e12, 4), plan=v.get("plan")) for k, v in kr.items()},
                seconds_total=round(time.perf_counter() - t0, 1))
@@ -554,7 +583,8 @@ def _tp_child(n: int, args, extra_env: dict, timeout_s: int = 0) -> dict:
         return dict(error=f"rc {out.returncode}", stderr=out.stderr[-400:])
     d = json.loads(lines[-1])
     keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "mean_accepted_len", "rccl_ranks", "config",
-            "roofline", "step_roofline", "allreduce", "prefill_steps_in_timed_region")
+            "roofline", "step_roofline", "allreduce", "prefill_steps_in_timed_region", "value_steady", "steady_ms_per_step",
+            "tp_bytes_per_rank")
     res = {k: d[k] for k in keep if k in d}
     if "config" in d:
         res["step_loop"] = d["config"].get("step_loop")
@@ -624,6 +654,10 @@ def main():
     ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each `other_configs` run")
     ap.add_argument("--no-reference-metric", action="store_true",
                     help="skip the whole-prompt run behind `value_reference_metric` / `prefill_step_ms`")
+    ap.add_argument("--steady-window", action="store_true",
+                    help="time K steps wherever the warm-up left the loop (steady steps only for K <= ~30) instead of starting "
+                         "the timed window at a fresh prompt")
+    ap.add_argument("--no-config-e", action="store_true", help="skip configuration E (70B target at TP = 1) in `other_configs`")
     ap.add_argument("--no-tp-extra", action="store_true",
                     help="N > 1: skip the secondary run of configuration E (70B target tensor-parallel over the N GPUs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
@@ -673,6 +707,12 @@ def main():
     from sequoia_amd.Tree._native_tree import QUIRK_STEPS
     commit_order = args.commit_order
     loop.run_steps(args.warmup)
+    # The timed window is the reference's metric (tests/testbed.py:78-95): K consecutive speculation steps of the harness
+    # loop BEGINNING WITH A FRESH PROMPT, so the prefill-bearing first verify of a prompt (255 rows through the target) is
+    # inside it, as it is inside the reference's timer; `value_steady` / `steady_ms_per_step` are the same window without
+    # its prefill-bearing steps (rounds 1-4 quoted that as `value`).  --steady-window keeps the old window.
+    if not args.steady_window:
+        loop.start_fresh_prompt()
     QUIRK_STEPS[0] = 0           # counted over the timed steps only (config.commit_order_quirk_steps)
     if tp_mode and world > 1:
         from sequoia_amd.Engine.ts_linear import assert_same_plans_across_ranks
@@ -680,10 +720,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    p0 = loop.prefill_steps
+    p0, ps0, pt0 = loop.prefill_steps, loop.prefill_seconds, loop.prefill_tokens
     secs, new_tok, steps = loop.run_steps(args.steps)
     torch.cuda.synchronize()
     prefill_steps = loop.prefill_steps - p0      # steps of the timed region that carried a prompt's target prefill
+    prefill_secs, prefill_tok = loop.prefill_seconds - ps0, loop.prefill_tokens - pt0
+    steady_steps = max(steps - prefill_steps, 1)
+    steady_ms = (secs - prefill_secs) / steady_steps * 1e3
+    value_steady = (new_tok - prefill_tok) / max(secs - prefill_secs, 1e-9)
     rccl_ranks = 1
     allreduce = None
     if world > 1:
@@ -704,6 +748,7 @@ def main():
         print(json.dumps(dict(metric="accepted tokens/sec", value=new_tok / secs, unit="tokens/s", n_gpus=world, steps=args.steps,
                               warmup=args.warmup, ms_per_step=secs / args.steps * 1e3, higher_is_better=True, dtype="f16",
                               data="synthetic", mean_accepted_len=new_tok / steps_all, roofline=None, cpu_baseline=None,
+                              value_steady=value_steady, steady_ms_per_step=steady_ms, prefill_steps_in_timed_region=prefill_steps,
                               note="--no-kernel-rooflines: profiling aid, not a benchmark line",
                               config=dict(workload=f"config {args.config}", commit_order=commit_order))))
         if world > 1:
@@ -804,9 +849,9 @@ def main():
             del loop4
         wb = step_weight_bytes(loop, gm)
         step_roof = dict(weight_bytes=wb["total"], target_bytes=wb["target"], draft_bytes_per_forward=wb["draft"],
-                         draft_forwards=wb["draft_forwards"], achieved=wb["total"] / (secs / args.steps) / 1e9, peak=8000.0,
-                         unit="GB/s", frac=wb["total"] / (secs / args.steps) / 8e12,
-                         note="projection + lm_head weight bytes one speculation step streams (rank-local), over ms_per_step")
+                         draft_forwards=wb["draft_forwards"], achieved=wb["total"] / (steady_ms * 1e-3) / 1e9, peak=8000.0,
+                         unit="GB/s", frac=wb["total"] / (steady_ms * 1e-3) / 8e12,
+                         note="projection + lm_head weight bytes one speculation step streams (rank-local), over steady_ms_per_step")
         other = None
         if (not args.no_other_configs and world == 1 and args.config == "B" and not args.growmap and args.pair == "calibrated"
                 and not args.sync_loop and not args.no_graphs):
@@ -815,13 +860,18 @@ def main():
                 other["C"], _ = run_other_config("C", args, device, prompts, engines=(draft, target), steps=args.other_steps)
             except Exception as e:
                 other["C"] = dict(error=f"{type(e).__name__}: {e}")
-            try:
-                import gc
-                other["D"], eng_d = run_other_config("D", args, device, prompts, steps=args.other_steps)
-                del eng_d
+            import gc
+            for oc, osteps in (("D", args.other_steps), ("E", min(args.other_steps, 12))):
+                if oc == "E" and args.no_config_e:
+                    continue
+                try:
+                    other[oc], eng_o = run_other_config(oc, args, device, prompts, steps=osteps, warmup=5 if oc == "D" else 3)
+                    from sequoia_amd.Tree.step_graph import StepState
+                    StepState.release(eng_o[1])
+                    del eng_o
+                except Exception as e:
+                    other[oc] = dict(error=f"{type(e).__name__}: {e}")
                 gc.collect(); torch.cuda.empty_cache()
-            except Exception as e:
-                other["D"] = dict(error=f"{type(e).__name__}: {e}")
         line = dict(metric="accepted tokens/sec", value=new_tok / secs, unit="tokens/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=secs / args.steps * 1e3,
                     higher_is_better=True, scaling="strong" if tp_mode else "weak", vs_baseline=None, dtype="f16", data="synthetic",
@@ -840,8 +890,18 @@ def main():
                                      "ts_plans_gfx950.json); prompt prefill and lm_head at 128 rows: PyTorch GEMM ("
                                      + ("TunableOp-selected hipBLASLt / rocBLAS solutions" if gemm_tuned else "default algorithm") + ")"),
                     mean_accepted_len=new_tok / steps_all, steps_per_s=steps_all / secs, rccl_ranks=rccl_ranks,
-                    prefill_steps_in_timed_region=prefill_steps, allreduce=allreduce,
+                    prefill_steps_in_timed_region=prefill_steps,
+                    prefill_step_ms_in_timed_region=(prefill_secs / prefill_steps * 1e3) if prefill_steps else None,
+                    value_steady=value_steady, steady_ms_per_step=steady_ms,
+                    value_note="`value` = tokens / seconds over the K timed steps of the harness loop starting at a fresh prompt: "
+                               "the reference's metric (tests/testbed.py:78-95, the prefill-bearing first verify inside the timer); "
+                               "`value_steady` = the same window without its prefill-bearing steps (what rounds 1-4 printed as `value`); "
+                               "`value_reference_metric` = the same metric over 3 whole prompts",
+                    allreduce=allreduce,
                     roofline=roof, step_roofline=step_roof, kernels=kernels,
+                    tp_bytes_per_rank=(tp_bytes_per_rank(dict(wb, target=wb["target"] * world,
+                                                              draft=wb["draft"] * (world if os.environ.get("SEQUOIA_TP_DRAFT", "0") == "1" else 1)))
+                                       if tp_mode else None),
                     value_reference_metric=ref_metric["value"] if ref_metric else None,
                     prefill_step_ms=ref_metric["prefill_step_ms"] if ref_metric else None, reference_metric=ref_metric,
                     other_configs=other, host_driven_loop=host_loop, mi355x_growmap=tuned,

@@ -126,6 +126,7 @@ class Loop:
         self.cur_len = 0
         self.prefill_steps = 0       # steps that carried a prompt's target prefill (the first verify of every prompt)
         self.prefill_seconds = 0.0   # wall time of those steps (construct_grow_map + verify; verify ends on a result read)
+        self.prefill_tokens = 0      # tokens those steps committed
         self.prompts_done = 0        # prompts generated to the end (max_new tokens, EOS, or a terminal step)
         # device-driven steps under tensor parallelism too: the step block, the result ring and the decisions are per
         # rank and identical on every rank (replicated draft / sampler / verifier, same noise), so every rank replays
@@ -146,14 +147,20 @@ class Loop:
                              **(dict(step_graph=True) if self.pipelined else {}))
         self.cur_len = len(p)
 
+    def start_fresh_prompt(self):
+        """Drop a prompt that run_steps() left half-way: the next step is the prefill-bearing first step of a new prompt
+        (bench.py starts its timed window there, so the window holds the steps tests/testbed.py:78-95 times -- the first
+        verify of a prompt with its target prefill included -- not only steady ones)."""
+        if self.tree is not None:
+            if self.pipelined and getattr(self.tree, "_pipe", None) is not None:
+                self.tree.end_pipeline()
+            self.tree = None
+
     def run_prompts(self, n_prompts, max_steps=100000):
         """Run until n_prompts more prompts are complete (each from its prefill-bearing first step to max_new tokens / EOS):
         the reference's metric as tests/testbed.py:78-95 computes it -- total_time / tokens over WHOLE prompts, the
         target prefill inside the first verify included.  Returns (seconds, new_tokens, steps)."""
-        if self.tree is not None:          # a prompt left half-way by run_steps(): start from a fresh one
-            if self.pipelined and getattr(self.tree, "_pipe", None) is not None:
-                self.tree.end_pipeline()
-            self.tree = None
+        self.start_fresh_prompt()          # a prompt left half-way by run_steps(): start from a fresh one
         return self.run_steps(max_steps, stop_after_prompts=self.prompts_done + n_prompts)
 
     def run_steps(self, k_steps, on_step=None, on_accept=None, stop_after_prompts=None):
@@ -188,10 +195,11 @@ class Loop:
                     t_p = time.perf_counter()
                     tree.construct_grow_map()
                     valid, a, _, terminate = tree.verify()
+                    length = valid.shape[0]
                     if is_prefill:
                         self.prefill_steps += 1
                         self.prefill_seconds += time.perf_counter() - t_p
-                    length = valid.shape[0]
+                        self.prefill_tokens += length - self.cur_len
                     last = int(valid[-1])              # the reference's EOS test reads the last token (tests/testbed.py:80)
                     if on_step is not None:
                         on_step(tree, terminate)
