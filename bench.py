@@ -459,13 +459,14 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
         tok_per_step = (sum(step_tok[1:]) / n_steady) if n_steady else None
         # the imported reference beside this port on the same weights / prompt / noise (oracle/ref_cpu_baseline.py, run in
         # the build container: the reference checkout does not travel): seconds-per-step ratio, to scale `value`
-        ref_over_port = None
+        ref_over_port = ref_record = None
         try:
             import glob
             newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_cpu_reference_vs_port.json")))[-1]
             with open(newest) as f:
                 rp = json.load(f)
             ref_over_port = rp["reference"]["steps_per_s"] / rp["port"]["steps_per_s"]
+            ref_record = os.path.basename(newest)          # which round's container run the ratio comes from
         except (OSError, KeyError, ValueError, ZeroDivisionError, IndexError):
             pass
         return dict(value=(tok_per_step / best_s) if n_steady else None, unit="tokens/s", cores=best_thr,
@@ -480,7 +481,7 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
                     steps_per_s=(1.0 / best_s) if n_steady else None, prefill_step_s=step_s[0],
                     step_seconds=[round(x, 3) for x in step_s], step_threads=step_thr, step_tokens=step_tok,
                     seconds_per_step_by_threads={str(t): round(v, 3) for t, v in mean_by_thr.items()},
-                    reference_over_port=ref_over_port, host_cores=avail, tokens=valid[:cur].tolist())
+                    reference_over_port=ref_over_port, reference_over_port_record=ref_record, host_cores=avail, tokens=valid[:cur].tolist())
     finally:
         ops_mod.set_ops_for_testing(prev)
         torch.set_num_threads(prev_threads)

@@ -11,8 +11,6 @@ has no weights, a seeded random init of a named architecture ("random:<arch>[:se
 """
 from __future__ import annotations
 
-import glob
-import json
 import os
 from dataclasses import dataclass
 
@@ -119,32 +117,52 @@ class LlamaWeights:
         self.norm = None
         self.lm_head = None
 
-    # ---- from a HF-style state dict (names as in the reference's LlamaForCausalLM_*) -------------
+    # ---- from a HF-style state dict / a streamed checkpoint directory (names as in the reference's LlamaForCausalLM_*) ----
     @staticmethod
     def from_state_dict(sd, dims: LlamaDims, dtype, device) -> "LlamaWeights":
+        from .checkpoint import StateDictSource
+        return LlamaWeights.from_source(StateDictSource(sd), dims, dtype, device)
+
+    @staticmethod
+    def from_source(src, dims: LlamaDims, dtype, device) -> "LlamaWeights":
+        """Fused, sharded weights from a tensor source (Engine/checkpoint.py).  Every rank asks the source for the slices it
+        owns only -- column-parallel projections by output rows, row-parallel ones by input columns, K / V by KV-head
+        group, lm_head by vocabulary rows -- and each fused tensor goes to the device before the next one is read."""
         w = LlamaWeights(dims, dtype, device)
         r, ws = dims.tp_rank, dims.tp_world
-        g = lambda k: torch.as_tensor(sd[k]).to(dtype)
-        put = lambda t: t.to(device).contiguous()
-        w.embed = put(g("model.embed_tokens.weight"))
+        put = lambda t: t.to(dtype).to(device).contiguous()
+
+        def rows(name, rank, world):
+            n = src.shape(name)[0]
+            assert n % world == 0, f"{name}: {n} rows do not split over {world} ranks"
+            per = n // world
+            return src.rows(name, rank * per, (rank + 1) * per) if world > 1 else src.full(name)
+
+        def cols(name, rank, world):
+            n = src.shape(name)[1]
+            assert n % world == 0, f"{name}: {n} columns do not split over {world} ranks"
+            per = n // world
+            return src.cols(name, rank * per, (rank + 1) * per) if world > 1 else src.full(name)
+
+        w.embed = put(src.full("model.embed_tokens.weight"))
+        kv_world = min(ws, dims.num_key_value_heads)
+        kv_rank = r * kv_world // ws
         for i in range(dims.num_hidden_layers):
             p = f"model.layers.{i}."
-            q = _shard_rows(g(p + "self_attn.q_proj.weight"), r, ws)
-            kv_world = min(ws, dims.num_key_value_heads)
-            kv_rank = r * kv_world // ws
-            k = _shard_rows(g(p + "self_attn.k_proj.weight"), kv_rank, kv_world)
-            v = _shard_rows(g(p + "self_attn.v_proj.weight"), kv_rank, kv_world)
-            gate = _shard_rows(g(p + "mlp.gate_proj.weight"), r, ws)
-            up = _shard_rows(g(p + "mlp.up_proj.weight"), r, ws)
             w.layers.append(LayerWeights(
-                ln1=put(g(p + "input_layernorm.weight")),
-                wqkv=put(torch.cat([q, k, v], dim=0)),
-                wo=put(_shard_cols(g(p + "self_attn.o_proj.weight"), r, ws)),
-                ln2=put(g(p + "post_attention_layernorm.weight")),
-                w_gate_up=put(torch.cat([gate, up], dim=0)),
-                w_down=put(_shard_cols(g(p + "mlp.down_proj.weight"), r, ws))))
-        w.norm = put(g("model.norm.weight"))
-        w.lm_head = put(_shard_rows(g("lm_head.weight"), r, ws))
+                ln1=put(src.full(p + "input_layernorm.weight")),
+                wqkv=put(torch.cat([rows(p + "self_attn.q_proj.weight", r, ws).to(dtype),
+                                    rows(p + "self_attn.k_proj.weight", kv_rank, kv_world).to(dtype),
+                                    rows(p + "self_attn.v_proj.weight", kv_rank, kv_world).to(dtype)], dim=0)),
+                wo=put(cols(p + "self_attn.o_proj.weight", r, ws)),
+                ln2=put(src.full(p + "post_attention_layernorm.weight")),
+                w_gate_up=put(torch.cat([rows(p + "mlp.gate_proj.weight", r, ws).to(dtype),
+                                         rows(p + "mlp.up_proj.weight", r, ws).to(dtype)], dim=0)),
+                w_down=put(cols(p + "mlp.down_proj.weight", r, ws))))
+        w.norm = put(src.full("model.norm.weight"))
+        # tied embeddings (no lm_head.weight in the checkpoint): the head is the embedding matrix
+        head = "lm_head.weight" if src.has("lm_head.weight") else "model.embed_tokens.weight"
+        w.lm_head = put(rows(head, r, ws))
         return w
 
     # ---- seeded random init (HF initializer_range = 0.02), generated on the target device --------
@@ -241,20 +259,16 @@ def load_weights(spec, dtype, device, tp_world=1, tp_rank=0, vocab_size=32000):
     if kind == "state":
         dims = LlamaDims.from_any(payload["config"], tp_world=tp_world, tp_rank=tp_rank)
         return LlamaWeights.from_state_dict(payload["state_dict"], dims, dtype, device)
-    # HF directory
-    with open(os.path.join(payload, "config.json")) as f:
-        cfg = json.load(f)
-    dims = LlamaDims.from_any(cfg, tp_world=tp_world, tp_rank=tp_rank)
-    files = sorted(glob.glob(os.path.join(payload, "*.safetensors")))
-    if not files:
-        raise FileNotFoundError(f"no *.safetensors under {payload}")
-    from safetensors.torch import load_file
-    sd = {}
-    for fpath in files:
-        sd.update(load_file(fpath, device="cpu"))
-    if "lm_head.weight" not in sd:
-        sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
-    return LlamaWeights.from_state_dict(sd, dims, dtype, device)
+    # HF directory: config.json + *.safetensors, streamed slice by slice (every rank reads its own shard only)
+    from .checkpoint import CheckpointDirSource, read_config
+    dims = LlamaDims.from_any(read_config(payload), tp_world=tp_world, tp_rank=tp_rank)
+    src = CheckpointDirSource(payload)
+    try:
+        w = LlamaWeights.from_source(src, dims, dtype, device)
+        w.checkpoint_bytes_read = src.bytes_read
+    finally:
+        src.close()
+    return w
 
 
 class _LlamaForCausalLM:
