@@ -848,6 +848,25 @@ def main():
                                    "prefill) outside the timer like tests/testbed.py:67-79; the first verify of every prompt "
                                    "carries the 255-row target prefill")
             del loop4
+        # the package's DEFAULT commit order (`lossless`) on the same loop: what a user who does not ask for the reference's
+        # token stream gets -- same kernels and steps/s, its own token stream and therefore tokens / step
+        lossless = None
+        if commit_order != "lossless" and world == 1 and not args.no_reference_metric and cfg["mode"] == "stochastic":
+            _NT.COMMIT_ORDER = "lossless"
+            try:
+                draft.clear_kv(); target.clear_kv()
+                torch.manual_seed(17 + rank)
+                loop5 = Loop(cfg, draft, target, gm, device, prompts, use_graphs=not args.no_graphs,
+                             pipelined=not args.sync_loop and not args.no_graphs)
+                loop5.run_steps(args.warmup)
+                if not args.steady_window:
+                    loop5.start_fresh_prompt()
+                s5, t5, k5 = loop5.run_steps(args.steps)
+                lossless = dict(commit_order="lossless (package default)", value=t5 / s5, unit="tokens/s", ms_per_step=s5 / k5 * 1e3,
+                                mean_accepted_len=t5 / k5, steps=k5)
+                del loop5
+            finally:
+                _NT.COMMIT_ORDER = commit_order
         wb = step_weight_bytes(loop, gm)
         step_roof = dict(weight_bytes=wb["total"], target_bytes=wb["target"], draft_bytes_per_forward=wb["draft"],
                          draft_forwards=wb["draft_forwards"], achieved=wb["total"] / (steady_ms * 1e-3) / 1e9, peak=8000.0,
@@ -905,7 +924,7 @@ def main():
                                        if tp_mode else None),
                     value_reference_metric=ref_metric["value"] if ref_metric else None,
                     prefill_step_ms=ref_metric["prefill_step_ms"] if ref_metric else None, reference_metric=ref_metric,
-                    other_configs=other, host_driven_loop=host_loop, mi355x_growmap=tuned,
+                    lossless_commit_order=lossless, other_configs=other, host_driven_loop=host_loop, mi355x_growmap=tuned,
                     autoregressive_baseline=autoreg,
                     cpu_baseline=cpu)
     if world > 1:

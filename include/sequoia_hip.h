@@ -441,7 +441,11 @@ int sq_allreduce_sum_slabs_f16(const void* slab, int splits, void* out, size_t n
 /* All-gather of the vocabulary-parallel lm_head (column-parallel over the ranks, Engine/Llama_model.py:280-283 on a
  * shard): slice = this rank's [rows][v] fp16 logits, out = the full [rows][world v] rows (rank r's columns at
  * [r v, (r + 1) v)), by direct peer stores into the same workspaces (their own area: rows world v <=
- * max_gather_elems, the value the workspace was sized with).  v % 8 == 0.                                          */
+ * max_gather_elems, the value the workspace was sized with).  v % 8 == 0.
+ * v must be THE SAME in consecutive gathers on one workspace unless the caller synchronises all ranks in between: the
+ * per-(peer, block) "read" handshake orders a gather behind the previous one row by row (rows are dealt to blocks by
+ * row % blocks), and a row's bytes in the peer's image sit at i world v + rank v -- with another v a block would overwrite
+ * bytes a different block of the peer may still be reading (Engine/xgmi_allreduce.py::gather_cols enforces it).        */
 int sq_allgather_cols_f16(const void* slice, void* out, int rows, int v, int rank, int world, void* const* ws,
                           size_t max_elems, size_t max_gather_elems, void* stream);
 /* All-reduce of a row-parallel projection + the decoder layer's continuation in ONE launch (replaces the all-reduce

@@ -166,6 +166,15 @@ class XgmiAllReduce:
                 peers.append((ph.value, nbytes))
         flags = [None] * world
         dist.all_gather_object(flags, failed, group=group)      # (also: every rank has mapped every object -> names may go)
+        # Every peer holds its mapping now: the NAME can go at once (the mappings stay valid after shm_unlink).  A worker that
+        # crashes or is killed later leaves nothing under /dev/shm, and a recycled pid can never collide with a leaked name
+        # (the objects used to be unlinked in close() only).
+        try:
+            import _posixshmem
+            _posixshmem.shm_unlink(name.decode())
+            name = None
+        except (ImportError, OSError):
+            pass                                                # close() unlinks it then
         shared = dict(name=name, host=host.value, bytes=nbytes, peers=peers)
         ar = XgmiAllReduce(lib, rank, world, ptrs, devp, [], max_elems, device, group, max_gather_elems, shared=shared)
         if any(flags):
@@ -287,6 +296,19 @@ class XgmiAllReduce:
     def gather_cols(self, slice_: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """[rows, v] per rank -> [rows, world v] on every rank (rank r's columns at [r v, (r + 1) v))."""
         rows, v = slice_.shape
+        # The per-(peer, block) "read" handshake protects the bytes a block overwrites in the peer's image only while the slice
+        # WIDTH is the one of the previous gather (offsets in the image are i W v + R v: another v moves every row).  The product
+        # path gathers one width per workspace (the vocabulary shard); a caller that changes it gets a full stop in between
+        # instead of a race (ADVICE r04), and inside a graph capture -- where no stop is possible -- a loud error.
+        last = getattr(self, "_gather_v", None)
+        if last is not None and last != v:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"all-gather width changed from {last} to {v} inside a graph capture: one width per workspace "
+                                   "between synchronisations (include/sequoia_hip.h, sq_allgather_cols_f16)")
+            torch.cuda.synchronize(self.device)
+            if dist.is_available() and dist.is_initialized():
+                dist.barrier(group=self.group)
+        self._gather_v = v
         if out is None:
             out = torch.empty((rows, self.world * v), dtype=slice_.dtype, device=slice_.device)
         native.check(self.lib.sq_allgather_cols_f16(slice_.data_ptr(), out.data_ptr(), rows, v, self.rank, self.world, self._table,

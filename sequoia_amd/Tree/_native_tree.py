@@ -374,6 +374,8 @@ class NativeTree(Tree):
             while int(rec[7]) != idx:
                 spins += 1
                 if (spins & 0xfff) == 0 and time.time() - t0 > timeout_s:
+                    if _xgmi._LIVE:
+                        _xgmi.raise_on_fault()       # a collective that gave up explains the missing record: say THAT
                     raise RuntimeError(f"step {idx}: no result record after {timeout_s} s")
         rec = rec.copy()
         if _xgmi._LIVE:

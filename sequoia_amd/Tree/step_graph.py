@@ -26,15 +26,20 @@ N_BONUS = 1024
 # "1": a forward on the tall-skinny path stages its own inputs in its first launch (sq_embed_stage_rmsnorm_f16) -- 7 launches per
 # step fewer; "0": sq_stage_tree_inputs in front of every forward
 FUSE_STAGE = os.environ.get("SEQUOIA_FUSE_STAGE", "1") == "1"
-# "1": the draft forward over the LAST tree level leaves the step's critical path.  Its nodes are leaves -- no child is ever
-# sampled from their draft rows (Tree/SpecTree.py:103) -- so the step needs only their KV rows (a leaf can be accepted and
-# then belongs to the next step's context), and needs them only at the KV compaction AFTER the verification.  The forward
-# therefore (a) stops after its last layer's RoPE + KV write (no attention / o_proj / MLP of the last layer, no final norm,
-# no lm_head, no row statistics: TreeContext.need_logits = False) and (b) is captured on a forked stream, concurrent with
-# the target's verify forward, joined before the verifier runs.  Committed tokens are identical by construction (the draft
-# rows of leaves are never read); "0" restores the serial form.
-OVERLAP_LAST_LEVEL = os.environ.get("SEQUOIA_OVERLAP_LAST_LEVEL", "1") == "1"
-
+# The draft forward over the LAST tree level: its nodes are leaves -- no child is ever sampled from their draft rows
+# (Tree/SpecTree.py:103) -- so the step needs only their KV rows (a leaf can be accepted and then belongs to the next
+# step's context), not their logits.
+#   KV_ONLY_LAST_LEVEL ("1", default): that forward stops after its last layer's RoPE + KV write (no attention / o_proj /
+#       MLP of the last layer, no final norm, no lm_head, no row statistics: TreeContext.need_logits = False).  Committed
+#       tokens are identical by construction (the draft rows of leaves are never read); "0" runs the full forward.
+#   OVERLAP_LAST_LEVEL ("0", default): "1" additionally captures that forward on a forked stream, concurrent with the
+#       target's verify forward, joined before the verifier; "2" the same with the step captured on a high-priority stream
+#       and the fork on a low-priority one.  MEASURED NEGATIVE on MI355X (profiles/r05_overlap_last_level_not_adopted.md:
+#       config B 5.29 -> 5.40 ms / step, config D 12.03 -> 12.22): the target's projections need all 256 CUs in ONE
+#       resident wave of workgroups, and every draft kernel that holds a CU when such a launch starts stretches its tail
+#       by more than the draft forward saves.  Kept as an opt-in for other tree / model shapes.
+KV_ONLY_LAST_LEVEL = os.environ.get("SEQUOIA_KV_ONLY_LAST_LEVEL", "1") == "1"
+OVERLAP_LAST_LEVEL = os.environ.get("SEQUOIA_OVERLAP_LAST_LEVEL", "0")
 
 class _Fwd:
     """Static inputs of one forward of fixed q_len (the analogue of a _GraphRunner's buffers)."""
@@ -111,9 +116,9 @@ class StepState:
         depth = g["depth32"]
         dm, tm = self.draft.engine, self.target.engine
         n_levels = len(g["levels"])
+        kv_only = KV_ONLY_LAST_LEVEL and self.cuda and getattr(dm.model, "ts", None) is not None
         # (a sharded draft runs collectives: its forward stays on the step's one stream, in the ranks' common order)
-        overlap = (OVERLAP_LAST_LEVEL and self.cuda and getattr(dm.model, "ts", None) is not None
-                   and getattr(dm.model, "reduce_fn", None) is None)
+        overlap = kv_only and OVERLAP_LAST_LEVEL in ("1", "2") and getattr(dm.model, "reduce_fn", None) is None
         side = None
         for li, (lv, f) in enumerate(zip(g["levels"], self.fwd_levels)):
             first = lv["first_child"]
@@ -124,6 +129,11 @@ class StepState:
             else:
                 ops.topk(self.draft_logits, lv["row_ids"], lv["k"], out, branch=lv["branch"], out_off=lv["out_off"],
                          out_base=gt_dev)
+            if kv_only and not overlap and li == n_levels - 1 and lv["total"] <= TS_MAX_ROWS:
+                f.tree.need_logits = False                     # leaves: KV rows only
+                self._stage(f, first - 1, first - 1 + lv["total"])
+                dm.model_run(input_ids=f.ids, storage_ids=f.sto, position_ids=f.pos, attention_mask=None, tree=f.tree)
+                continue
             if overlap and li == n_levels - 1 and lv["total"] <= TS_MAX_ROWS:
                 # leaves: KV rows only, off the critical path.  The inputs are staged on the step's stream (the fork below
                 # orders the side stream behind them; the walker that rewrites `tokens` / the step block runs after the join)
@@ -168,7 +178,7 @@ class StepState:
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device, priority=0)      # (0 = the lowest priority)
         return self._side
 
     def _stage(self, f, rel_slot0, rel_kv_len, advance=False):
@@ -218,7 +228,8 @@ class StepState:
         torch.cuda.current_stream().wait_stream(s)
         self.step[SQ_STEP_GT] = 1
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        kw = dict(stream=torch.cuda.Stream(device=self.device, priority=-1)) if OVERLAP_LAST_LEVEL == "2" else {}
+        with torch.cuda.graph(graph, **kw):
             self.body()
         self.graph = graph
         for kv, off, dirty in marks:

@@ -62,16 +62,23 @@ struct ArParams {
 // word in pinned host memory that the host loop reads for free at every step (Tree/_native_tree.py::collect_step /
 // verify raise on it): a tensor-parallel job fails loudly at the step after the timeout instead of decoding on stale
 // partial sums (the status word used to be read by the self-check and bench.py only).
+// The external word takes a PLAIN system-scope store of the bits (any non-zero value raises on the host; a read-modify-write
+// to pinned host memory would need PCIe atomics, which not every platform routes -- ADVICE r04).
 __device__ __forceinline__ void ar_fault(char* mine, uint32_t bits) {
     atomicOr((uint32_t*)mine, bits);
     uint32_t* ext = *(uint32_t* const*)(mine + 8);
-    if (ext) __hip_atomic_fetch_or(ext, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ext) __hip_atomic_store(ext, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ void ar_flag_store(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ bool ar_flag_wait(const uint32_t* p, uint32_t want, uint32_t spin_limit) {
+// `mine`: this rank's workspace; once its status word is non-zero (an earlier wait of this job already gave up: a dead or
+// stalled peer) every later wait looks ONCE instead of spinning through its full bound again -- the rest of the step's
+// collectives (2 waits x 2 all-reduces x N layers) then cost microseconds, and the host's per-step fault check raises the
+// informative XgmiCollectiveTimeout before any generic time-out does.
+__device__ __forceinline__ bool ar_flag_wait(const uint32_t* p, uint32_t want, uint32_t spin_limit, const char* mine) {
+    if (__hip_atomic_load((const uint32_t*)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spin_limit = 1u;
     for (uint32_t it = 0; it < spin_limit; ++it) {
         // relaxed polls, ONE acquire after the hit (acquire loads in the loop cost 2-3x per hop); epochs only grow: a
         // peer that is already one call ahead has, by construction, finished this one
@@ -130,7 +137,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const Ar
 
     // ---- phase 2: reduce my chunk (rank order, fp32), publish it to every peer's area B ----------------------------------
     if (tid < W && tid != R) {
-        if (!ar_flag_wait((const uint32_t*)(mine + L.flags1) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit)) {
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags1) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit, mine)) {
             ar_fault(mine, 1u);
         }
     }
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_two_shot_kernel(const Ar
 
     // ---- phase 3: the other ranks' reduced chunks -> the caller's tensor ----------------------------------------------------
     if (tid < W && tid != R) {
-        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit)) {
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit, mine)) {
             ar_fault(mine, 2u);
         }
     }
@@ -349,7 +356,7 @@ __global__ void __launch_bounds__(AR_THREADS) allgather_cols_kernel(const AgPara
     const size_t ld = (size_t)W * P.v;
     // the peers have read the previous image out of their area C (word + 12 of the flag line = "read" epoch)
     if (tid < W && tid != R) {
-        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 12, epoch - 1, P.spin_limit))
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 12, epoch - 1, P.spin_limit, mine))
             ar_fault(mine, 8u);
     }
     __syncthreads();
@@ -370,7 +377,7 @@ __global__ void __launch_bounds__(AR_THREADS) allgather_cols_kernel(const AgPara
     if (tid < W && tid != R)
         ar_flag_store((uint32_t*)(P.ws[tid] + L.flags2) + ((size_t)R * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 8, epoch);
     if (tid < W && tid != R) {
-        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 8, epoch, P.spin_limit))
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE + 8, epoch, P.spin_limit, mine))
             ar_fault(mine, 4u);
     }
     __syncthreads();
@@ -488,7 +495,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_add_rmsnorm_kernel(const
 
     // ---- phase 2: reduce my rows (rank order, fp32, one rounding), publish them to every rank's area B (mine included) -----
     if (tid < W && tid != R) {
-        if (!ar_flag_wait((const uint32_t*)(mine + L.flags1) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit))
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags1) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit, mine))
             ar_fault(mine, 1u);
     }
     __syncthreads();
@@ -522,7 +529,7 @@ __global__ void __launch_bounds__(AR_THREADS) allreduce_add_rmsnorm_kernel(const
 
     // ---- phase 3: every chunk's rows of this block are complete here: residual add + RMSNorm --------------------------------
     if (tid < W && tid != R) {
-        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit))
+        if (!ar_flag_wait((const uint32_t*)(mine + L.flags2) + ((size_t)tid * AR_MAX_BLOCKS + b) * AR_FLAG_STRIDE, epoch, P.spin_limit, mine))
             ar_fault(mine, 2u);
     }
     __syncthreads();

@@ -175,7 +175,7 @@ def build_engines(z, meta, device):
     return draft, target
 
 
-def make_tree(z, meta, draft, target, device, cls=None, step_graph=None):
+def make_tree(z, meta, draft, target, device, cls=None, step_graph=None, commit_order="reference"):
     from sequoia_amd.growmap import GrowMap
     from sequoia_amd.Tree.GreedyTree import GreedyTree
     from sequoia_amd.Tree.SpecTree import SpecTree
@@ -193,7 +193,7 @@ def make_tree(z, meta, draft, target, device, cls=None, step_graph=None):
                position_ids=torch.zeros(M, device=device).long(), residual_graph=None, sampling_callables=None,
                sample_gather_indices=None, vocab_size=meta["vocab"],
                bonus_uniforms=[int(x) for x in z["bonus_u24"]], step_graph=step_graph,
-               commit_order="reference")        # the traces are runs of the reference itself (bonus stored before the gather)
+               commit_order=commit_order)       # "reference": the traces are runs of the reference itself (bonus stored before the gather)
     if meta["mode"] == "specinfer":
         tree.draw_uniforms = [z["draw_u24"][i] for i in range(z["draw_u24"].shape[0])]     # the trace's uniforms, per step
     if meta["mode"] == "greedys":

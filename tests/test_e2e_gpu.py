@@ -147,3 +147,39 @@ def test_tall_skinny_draft_forward_matches_general_path():
     assert (outs[0] - outs[1]).abs().max() < 6e-2          # logits of magnitude ~10: a few fp16 ulps
     assert (outs[0].argmax(-1) == outs[1].argmax(-1)).float().mean() > 0.9
     assert (caches[0] - caches[1]).abs().max() < 2e-2
+
+
+@pytest.mark.parametrize("name", ["B_seq128", "V32k_seq128", "L_S256"])
+def test_lossless_commit_order_replay_matches_oracle(name):
+    """The package DEFAULT commit order (`lossless`: accepted tokens gathered first, then the bonus token; ADVICE r04: the
+    default path must have trace coverage of its own).  Every step of the native loop on a trace's weights / prompt / noise
+    must equal the oracle's verification of the step's own inputs with gather_first=True, and the committed text must be
+    exactly the accepted path + the bonus token -- no bonus id over an accepted token, whichever slot it sat in."""
+    from oracle import ops_np as O
+    z, meta = load_trace(name)
+    draft, target = build_engines(z, meta, DEV)
+    tree = make_tree(z, meta, draft, target, DEV, commit_order="lossless")
+    succ, n, T = meta["successors"], len(meta["successors"]), meta["T"]
+    r16 = tree.r.cpu().numpy()
+    quirk_candidates = 0
+    for s in range(int(z["n_steps"])):
+        tree.construct_grow_map()
+        gt = tree.ground_truth_len
+        tokens_pre = tree.tokens.cpu().numpy().copy()
+        dl = tree.draft_logits[:n].cpu().numpy().copy()
+        valid, a, _, term = tree.verify()
+        tl = tree.target_logits.cpu().numpy()
+        want_tokens = tokens_pre.copy()
+        res = O.verify_stochastic(tl, dl.copy(), want_tokens, r16, succ, gt, T, int(z["bonus_u24"][s]), gather_first=True)
+        assert res["accept_len"] == int(a) and bool(res["terminal"]) == bool(term), f"{name} step {s}"
+        got = valid.cpu().numpy()
+        assert np.array_equal(got, want_tokens[:got.shape[0]]), f"{name} step {s}: committed tokens differ from the oracle's lossless order"
+        slots = res["slots"]
+        assert np.array_equal(got[gt:a], tokens_pre[slots]), f"{name} step {s}: the committed text is not the accepted path"
+        if not term:
+            assert got[a] == res["bonus"]
+        quirk_candidates += int(a in slots)              # steps where the reference's order would have committed a bonus id
+        if term:
+            break
+    assert tree.quirk_steps == 0
+    print(f"{name}: lossless replay == oracle in every step; {quirk_candidates} step(s) where the reference order would differ")
