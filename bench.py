@@ -386,6 +386,51 @@ def pmc_lookup(pmc_key, dom):
     return None, None, None, "no valid PMC record for " + pmc_key + ": " + "; ".join(notes) + " -- re-run tools/pmc_r04.sh"
 
 
+def pmc_northstar(growmap_levels):
+    """HBM-side bytes per step of the kernels BASELINE.json's north_star names -- the samplers (statistics + parts + merge
+    launches of every tree level) and the verifier (nodes + walk) -- from the newest profiles/r*_pmc_northstar.json
+    (tools/gpu_r05.sh pmc_ns: rocprofv3 PMC passes over tools/kbench.py, FETCH_SIZE / WRITE_SIZE separately, 2 FETCH + WRITE).
+    Records are keyed by (kernel, grid): a level of R parent rows launches R x 8 parts of 256 threads.  The record must have
+    been measured on this tree's sampler.hip / verify.hip.  -> {kernels-key: dict(traffic, pmc_file) or dict(traffic=None, note)}"""
+    import glob
+    out = {}
+    want = {"sampler.hip": source_sha("sampler.hip", "common.h"), "verify.hip": source_sha("verify.hip", "common.h")}
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_northstar.json")), reverse=True):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+        except (OSError, ValueError):
+            continue
+        have = pm.get("source_sha") or {}
+        K = pm.get("kernels", {})
+
+        def one(sub, grid=None, flavour=None):
+            for k, v in K.items():
+                if sub in k and (grid is None or v.get("grid") == grid) and (flavour is None or flavour in k) and v.get("hbm_bytes_per_launch") is not None:
+                    return v["hbm_bytes_per_launch"]
+            return None
+        rel = os.path.relpath(path, REPO)
+        if have.get("verify.hip") == want["verify.hip"] and "verify_stochastic" not in out:
+            a, b = one("verify_nodes_kernel"), one("verify_walk_kernel")
+            if a is not None and b is not None:
+                out["verify_stochastic"] = dict(traffic=a + b, pmc_file=rel)
+        if have.get("sampler.hip") == want["sampler.hip"] and "sample_wor_all_levels" not in out:
+            tot, ok = 0, True
+            for rows in growmap_levels:
+                parts = one("sample_parts_kernel", rows * 8 * 256, "ILi1E")
+                stats = one("logits_stats_kernel", rows * 8 * 256)
+                merge = one("sample_merge_rank_kernel", rows * 256)
+                if None in (parts, stats, merge):
+                    ok = False
+                    break
+                tot += parts + stats + merge
+            if ok:
+                out["sample_wor_all_levels"] = dict(traffic=tot, pmc_file=rel)
+    for k, src in (("verify_stochastic", "verify.hip"), ("sample_wor_all_levels", "sampler.hip")):
+        out.setdefault(k, dict(traffic=None, traffic_note=f"no profiles/r*_pmc_northstar.json record measured on this tree's {src}"))
+    return out
+
+
 def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=False):
     """The CPU path timed on this box's host cores: the same host loop with the reference's PyTorch op sequences
     restated for CPU tensors (oracle/ops_torch_cpu.py; verification on the numpy oracle) and PyTorch CPU GEMMs, fp16
@@ -789,6 +834,13 @@ def main():
                            frac=v["bytes"] / v["seconds"] / 1e9 / peak_hbm, algorithmic_bytes=v["bytes"],
                            launches_per_step=v["launches_per_step"], per_step_us=per_step[k] * 1e6,
                            **{kk: v[kk] for kk in ("inputs", "plan", "kv_len") if kk in v}) for k, v in kr.items()}
+        if args.config == "B" and cfg["mode"] == "stochastic":
+            # PMC traffic of the north-star kernels (per step), next to their algorithmic bytes
+            for k, rec in pmc_northstar([len(lv.row_ids) for lv in gm.levels]).items():
+                if k in kernels:
+                    kernels[k].update(rec)
+                    if rec.get("traffic"):
+                        kernels[k]["traffic_over_algorithmic"] = round(rec["traffic"] / kernels[k]["algorithmic_bytes"], 3)
         tuned = None
         tuned_name = "MI355X-synthetic-68m-7b-stochastic"
         if not args.no_tuned_growmap and world == 1 and args.config == "B" and not args.growmap and args.pair == "calibrated":

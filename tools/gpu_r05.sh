@@ -42,6 +42,8 @@ for stage in "$@"; do
   overlap)     # the forked last draft level: whole-step graphs of the traces whose draft runs the tall-skinny path
     timeout 1200 python -m pytest tests/test_step_pipeline_gpu.py -m gpu -q -k "V32k_seq128 or B_topp09 or D_13b_w4 or E_70b_w2 or L_S256_v32k or config_b or eos" > $O/tests_overlap.log 2>&1
     grep -n "passed\|failed\|rror" $O/tests_overlap.log | tail -8 ;;
+  lossless)
+    timeout 900 python -m pytest tests/test_e2e_gpu.py -m gpu -q -k "lossless" > $O/tests_lossless.log 2>&1; tail -3 $O/tests_lossless.log | cut -c1-300 ;;
   kernels)
     timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q > $O/tests_kernels.log 2>&1; tail -3 $O/tests_kernels.log ;;
   tests)
@@ -81,7 +83,7 @@ for stage in "$@"; do
   exp:*)
     spec=${stage#exp:}; name=${spec%%=*}; envs=${spec#*=}
     ( IFS=,; for kv in $envs; do export "$kv"; done; unset IFS
-      timeout 600 python bench.py --config ${BENCH_CONFIG:-B} --steps ${BENCH_STEPS:-60} --warmup 8 ${BENCH_ARGS:---no-kernel-rooflines --no-cpu-baseline --no-tuned-growmap --no-autoregressive --no-other-configs --no-reference-metric} > $O/exp_$name.json 2> $O/exp_$name.err )
+      timeout 600 python bench.py --config ${BENCH_CONFIG:-B} --steps ${BENCH_STEPS:-200} --warmup 8 ${BENCH_ARGS:---steady-window --no-kernel-rooflines --no-cpu-baseline --no-tuned-growmap --no-autoregressive --no-other-configs --no-reference-metric} > $O/exp_$name.json 2> $O/exp_$name.err )
     line $O/exp_$name.json ;;
   *) echo "unknown stage $stage" ;;
   esac
