@@ -369,16 +369,28 @@ class _LlamaForCausalLM:
     def _forward_chunked(self, input_ids, q_len, pos, storage_ids, dense, tree, kv_cache):
         """More than MAX_ROWS new tokens when the fragment-major images are the only copy of the weights (exclusive
         mode): the rows run as consecutive chunks of <= MAX_ROWS.  A chunk's queries see the earlier chunks through the
-        KV cache (causal prefix / tree mask by slot), so the result equals the one-pass forward up to accumulation order."""
+        KV cache (causal prefix / tree mask by slot: a tree node's ancestors have smaller ids, i.e. sit in the same or an
+        earlier chunk), so the result equals the one-pass forward up to accumulation order.  Legal inside a captured step
+        (verify forwards of the 193- / 256- / 512-node growmaps on a target in exclusive mode)."""
         outs = []
         for r0 in range(0, q_len, TS_MAX_ROWS):
             r1 = min(q_len, r0 + TS_MAX_ROWS)
             sub_tree, sub_dense = None, None
             if tree is not None:
+                # a captured forward reads {q_slot0, gt, kv_len} from its device block: the chunk's block is that one shifted
+                # by the chunk's rows (a device-side add: replayable), its host scalars likewise
+                sub_ctx = None
                 if tree.ctx is not None:
-                    raise RuntimeError("chunked forwards cannot replay from a captured context block")
+                    key = (r0, (r1 - q_len) if tree.contiguous_slots else 0, str(tree.ctx.device))
+                    cache = self.__dict__.setdefault("_chunk_shift", {})
+                    shift = cache.get(key)
+                    if shift is None:      # made once, outside any capture (the eager warm-up of a graph comes first)
+                        if torch.cuda.is_current_stream_capturing():
+                            raise RuntimeError("chunked forward: run the forward eagerly once before capturing it")
+                        shift = cache[key] = torch.tensor([key[0], 0, key[1]], dtype=torch.int32, device=tree.ctx.device)
+                    sub_ctx = tree.ctx + shift
                 sub_tree = TreeContext(q_slot0=tree.q_slot0 + r0, gt=tree.gt, n_tree=tree.n_tree, bitmask=tree.bitmask,
-                                       kv_len=tree.q_slot0 + r1 if tree.contiguous_slots else tree.kv_len,
+                                       kv_len=tree.q_slot0 + r1 if tree.contiguous_slots else tree.kv_len, ctx=sub_ctx,
                                        contiguous_slots=tree.contiguous_slots)
             else:
                 sub_dense = dense[r0:r1]

@@ -174,3 +174,33 @@ def test_step_graph_with_separate_staging_launches(monkeypatch):
     tree.end_pipeline()
     torch.cuda.synchronize()
     assert np.array_equal(tree.tokens[:want[-1][0] + 1].cpu().numpy(), want[-1][1])
+
+
+def test_step_graph_with_chunked_verify_in_exclusive_mode(monkeypatch):
+    """A target whose fragment-major images are its only weights (SEQUOIA_TS_EXCLUSIVE=1: the 70B-on-few-GPUs mode) has no
+    hipBLASLt path: a verify forward of more than 144 rows (the 256-node growmap) runs as consecutive <= 144-row chunks of the
+    tall-skinny kernel, each reading the captured forward's context block shifted by its rows.  Whole-step graphs must commit
+    the tokens of the synchronous steps of the ordinary (two-copy) engines -- which replay the reference's trace."""
+    name = "L_S256_v32k"
+    z, meta = load_trace(name)
+    n_steps = int(z["n_steps"])
+    want = _sync_run(z, meta, n_steps)
+    monkeypatch.setenv("SEQUOIA_TS_EXCLUSIVE", "1")
+    draft, target = build_engines(z, meta, DEV)
+    assert target.engine.model.ts is not None and target.engine.model.ts.exclusive
+    tree = make_tree(z, meta, draft, target, DEV, step_graph=True)
+    assert tree.state is not None and tree.state.graph is not None
+    tree.construct_grow_map()
+    valid, a, _, term = tree.verify()
+    assert int(a) == want[0][0] and np.array_equal(valid.cpu().numpy(), want[0][1])
+    tree.begin_pipeline()
+    s = 1
+    while s < n_steps:
+        while (tree.can_enqueue(meta["M"]) and len(tree._pipe["inflight"]) < 2 and s + len(tree._pipe["inflight"]) < n_steps):
+            tree.enqueue_step()
+        a, n_acc, bonus, term = tree.collect_step()
+        assert a == want[s][0] and bonus == int(want[s][1][-1]), f"{name} step {s}"
+        s += 1
+    tree.end_pipeline()
+    torch.cuda.synchronize()
+    assert np.array_equal(tree.tokens[:want[-1][0] + 1].cpu().numpy(), want[-1][1])
