@@ -210,8 +210,10 @@ def _lonely_worker(rank, world, port, out_dir):
         x = torch.ones(4096, dtype=torch.float16, device="cuda:0")
         ar(x)
         torch.cuda.synchronize()                         # returns: the spin is bounded
-        # ... and the timeout does not pass silently: the kernel ORed its bits into the pinned fault word, which the
-        # speculation loop tests at every step (raise_on_fault) -- no device read involved
+        # ... and the timeout does not pass silently: the kernel stored its bits into the pinned fault word (a plain
+        # system-scope store: the word holds the bits of the LAST wait that gave up; any non-zero value raises), which the
+        # speculation loop tests at every step (raise_on_fault) -- no device read involved.  The workspace's own status
+        # word accumulates every phase that timed out; once it is set the later waits of the job look once, not spin.
         fault = int(ar.fault[0])
         raised = 0
         try:
@@ -230,7 +232,7 @@ def test_missing_peer_times_out_instead_of_hanging(tmp_path, monkeypatch):
     port = 34700 + (os.getpid() % 1500)
     mp.spawn(_lonely_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     status, fault, raised = (int(v) for v in np.load(tmp_path / "lonely.npy"))
-    assert status & 1 == 1 and fault & 1 == 1 and raised == 1
+    assert status & 1 == 1 and fault != 0 and raised == 1
 
 
 @pytest.mark.parametrize("name,world,fused_norm", [("E_64x2", 2, "1"), ("E_70b_w2", 2, "1"), ("E_64x2", 4, "1"), ("demo4", 4, "1"),
