@@ -42,6 +42,8 @@ for stage in "$@"; do
   overlap)     # the forked last draft level: whole-step graphs of the traces whose draft runs the tall-skinny path
     timeout 1200 python -m pytest tests/test_step_pipeline_gpu.py -m gpu -q -k "V32k_seq128 or B_topp09 or D_13b_w4 or E_70b_w2 or L_S256_v32k or config_b or eos" > $O/tests_overlap.log 2>&1
     grep -n "passed\|failed\|rror" $O/tests_overlap.log | tail -8 ;;
+  xgmi)
+    timeout 1500 python -m pytest tests/test_xgmi_allreduce_gpu.py -m gpu -q > $O/tests_xgmi.log 2>&1; tail -3 $O/tests_xgmi.log | cut -c1-300 ;;
   lossless)
     timeout 900 python -m pytest tests/test_e2e_gpu.py -m gpu -q -k "lossless" > $O/tests_lossless.log 2>&1; tail -3 $O/tests_lossless.log | cut -c1-300 ;;
   kernels)
