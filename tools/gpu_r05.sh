@@ -42,6 +42,11 @@ for stage in "$@"; do
   overlap)     # the forked last draft level: whole-step graphs of the traces whose draft runs the tall-skinny path
     timeout 1200 python -m pytest tests/test_step_pipeline_gpu.py -m gpu -q -k "V32k_seq128 or B_topp09 or D_13b_w4 or E_70b_w2 or L_S256_v32k or config_b or eos" > $O/tests_overlap.log 2>&1
     grep -n "passed\|failed\|rror" $O/tests_overlap.log | tail -8 ;;
+  tune70b)     # launch plans of the full-width 70B projections at 129 rows (configuration E at TP = 1): every (tiles, splits) candidate
+    for shape in qkv "o+res" "gate_up+silu" "down+res"; do
+      TS_ARCH=70b TS_ONLY="$shape" timeout 300 $GRAFT_REPO_ROOT/tools/ts_bench 129 >> $O/ts_tune_70b_129rows.log 2>&1
+    done
+    python tools/ts_tune_pick.py $O/ts_tune_70b_129rows.log ;;
   xgmi)
     timeout 1500 python -m pytest tests/test_xgmi_allreduce_gpu.py -m gpu -q > $O/tests_xgmi.log 2>&1; tail -3 $O/tests_xgmi.log | cut -c1-300 ;;
   lossless)

@@ -31,9 +31,13 @@ int main(int argc, char** argv) {
                              {"down+res", 4096, 11008, 0, 1}, {"lm_head", 32000, 4096, 0, 0}};
     const Shape shapes13[] = {{"qkv", 15360, 5120, 0, 0}, {"o+res", 5120, 5120, 0, 1}, {"gate_up+silu", 13824, 5120, 1, 0},
                               {"down+res", 5120, 13824, 0, 1}, {"lm_head", 32000, 5120, 0, 0}};
-    const Shape* shapes_p = a13 ? shapes13 : shapes7;
+    // TS_ARCH=70b: the FULL-WIDTH Llama-2-70b projections (configuration E at TP = 1: 64 query / 8 KV heads of 128, inter 28672)
+    const bool a70 = getenv("TS_ARCH") && !strcmp(getenv("TS_ARCH"), "70b");
+    const Shape shapes70[] = {{"qkv", 10240, 8192, 0, 0}, {"o+res", 8192, 8192, 0, 1}, {"gate_up+silu", 28672, 8192, 1, 0},
+                              {"down+res", 8192, 28672, 0, 1}, {"lm_head", 32000, 8192, 0, 0}};
+    const Shape* shapes_p = a70 ? shapes70 : (a13 ? shapes13 : shapes7);
     std::vector<Shape> shapes(shapes_p, shapes_p + 5);
-    const size_t slab_cap = 256ull << 20;
+    const size_t slab_cap = 512ull << 20;
     void* slab; CK(hipMalloc(&slab, slab_cap));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& sh : shapes) {
