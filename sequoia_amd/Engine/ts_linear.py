@@ -168,16 +168,28 @@ class TsLinearSet:
         torch.cuda.empty_cache()
 
     def default_plan(self, name, q_len):
-        """A launch shape that always works (exclusive mode cannot fall back to PyTorch's GEMM): about one workgroup per
-        compute unit, the widest column tiles the row count allows."""
+        """A launch shape that always works (exclusive mode cannot fall back to PyTorch's GEMM) for a shape nobody measured.
+        SwiGLU layers: one resident wave of workgroups, the widest column tiles the row count allows.  The other layer
+        projections follow what every measured plan of the 7B / 13B / 70B widths looks like (ts_plans_gfx950.json; round 5
+        found the old "256 workgroups x all of K" default 40-60 % slower than the tuned plans on the full-width 70B shapes,
+        where every workgroup then pulls the whole 2-7 MB activation image through its L2): about 4 column units per
+        workgroup and as many K-splits as make ~256 workgroups -- each workgroup reads 1 / splits of the activation image."""
         n_out, k, silu = self.shapes[name]
         units = n_out // 16
-        max_u = 3 if silu else (6 if q_len > 64 else 4)
-        tiles = max((units + max_u - 1) // max_u, min(units, 256))
-        splits = 1
-        if name in SPLITTABLE and not silu:       # (SwiGLU layers split K only by a measured plan)
+        if silu or name not in SPLITTABLE:
+            max_u = 3 if silu else (6 if q_len > 64 else 4)
+            return (max((units + max_u - 1) // max_u, min(units, 256)), 1)
+        if units < 256:                          # narrow layers (small drafts): one column unit group per workgroup, K split to ~192
+            max_u = 6 if q_len > 64 else 4
+            tiles = max((units + max_u - 1) // max_u, min(units, 256))
+            splits = 1
             while tiles * splits < 192 and splits < MAX_SPLITS and (k // 32) >= (splits + 1) * 8:
                 splits += 1
+            return (tiles, splits)
+        tiles = (units + 3) // 4
+        splits = max(1, min(SPLITS_CAP[name], (256 + tiles // 2) // tiles))
+        while splits > 1 and (k // 32) < splits * 8:
+            splits -= 1
         return (tiles, splits)
 
     def _images_fit(self, name) -> bool:
