@@ -59,8 +59,15 @@ constexpr int ts_merge_tiles(int mt, int nt) {
     return fit >= mt ? mt : fit;
 }
 
-template <int MT, int NT, int D, bool SILU>
-__global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P) {
+// TAIL: the activation block has 16 MT + 1 rows -- a tree of 2^k-ary levels plus its root: the 65-node 8x8 tree, the
+// 129-node 64x2 / 16x8 / ... trees of the reference's growmaps.  Rounding 129 rows up to 9 MFMA row tiles costs an eighth more
+// activation ingest and MFMA work and, above all, accumulator registers (9 x 8 tiles do not fit: <= 6 column tiles per
+// workgroup); 65 rows ran on the 6-tile build.  Here the 16 MT full tiles go through the MFMAs and the ONE extra row rides
+// beside them on the vector ALU: its 8 k-values of the lane's k-group (a 16-byte broadcast load from tile MT of the
+// fragment-major image, row 0) are multiplied into the weight fragment the lane holds anyway -- 4 v_dot2c_f32_f16 per column
+// tile and k-step, on the otherwise idle VALU -- and the 4 k-groups' partial dots meet by two lane shuffles at the end.
+template <int MT, int NT, int D, bool SILU, bool TAIL>
+__device__ __forceinline__ void ts_linear_body(const TsParams& P) {
     extern __shared__ float ts_lds[];                       // 4 waves x [MH*16][LDW] fp32 (MH = row tiles per merge pass)
     constexpr int LDW = NT * 16 + 4;                         // row stride: 16-byte aligned, 4 rows apart = 16 banks apart
     constexpr int TPU = SILU ? 2 : 1;                        // MFMA column tiles per 16-column output unit
@@ -89,6 +96,7 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) aoff[mt] = (uint32_t)min(mt, P.mtp - 1) * 1024u + (uint32_t)lane * 16u;
+    const uint32_t atoff = (uint32_t)MT * 1024u + (uint32_t)g * 256u;      // TAIL: row 16 MT = tile MT, r16 = 0, k-group g
     const uint32_t a_step = (TS_DBG & 1) ? 0u : (uint32_t)P.mtp * 1024u;
     const uint32_t w_shift = (TS_DBG & 2) ? 31u : 10u;
     const char* wbase = (const char*)P.w;
@@ -99,9 +107,12 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[mt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float tacc[TAIL ? NT : 1];                               // TAIL: this lane's partial dots of the extra row, per column tile
+#pragma unroll
+    for (int t = 0; t < (TAIL ? NT : 1); ++t) tacc[t] = 0.f;
 
     if (ks0 < ks1) {
-        half8 wr[D][NT], ar[D][MT];
+        half8 wr[D][NT], ar[D][MT], at[TAIL ? D : 1];
         // Step i of this wave's range is k-step ks0 + (i + rot) mod n: workgroups start at different places of K, so
         // at any moment they read different lines of the shared activation image instead of all walking it in
         // lockstep (measured: 1-3 % on the layer projections, 8-12 % on lm_head's 500 workgroups).  The rotation is a
@@ -115,12 +126,19 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
         _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                 \
             wr[d][t] = __builtin_nontemporal_load((const half8*)(wbase + (woff[t] + kw_)));            \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ar[d][mt] = *(const half8*)(abase + (aoff[mt] + ka_)); \
+        if (TAIL) at[d] = *(const half8*)(abase + (atoff + ka_));                                      \
     }
 #define TS_MMA(d)                                                                                      \
     {                                                                                                  \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
             _Pragma("unroll") for (int t = 0; t < NT; ++t)                                             \
                 acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[d][mt], wr[d][t], acc[mt][t], 0, 0, 0); \
+        if (TAIL) {                                                                                    \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                             \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+                    tacc[t] = __builtin_amdgcn_fdot2(half2v{at[d][2 * j], at[d][2 * j + 1]},           \
+                                                     half2v{wr[d][t][2 * j], wr[d][t][2 * j + 1]}, tacc[t], false); \
+        }                                                                                              \
     }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -128,6 +146,7 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
             else {
                 _Pragma("unroll") for (int t = 0; t < NT; ++t) wr[d][t] = half8{1, 1, 1, 1, 1, 1, 1, 1};
                 _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ar[d][mt] = half8{1, 1, 1, 1, 1, 1, 1, 1};
+                if (TAIL) at[d] = half8{1, 1, 1, 1, 1, 1, 1, 1};
             }
         }
         const int nfull = nst / D, rem = nst - nfull * D;
@@ -161,6 +180,56 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
         return;
     }
     const int groups = nu * 2;                                 // output items: (row, 8-column group); a unit holds 2
+    // one output item: the 4 wave images [img_rows][LDW] at ts_lds, summed in wave order, through the epilogue
+    auto emit = [&](int row, int img_row, int img_rows, int grp) {
+        const int unit = grp >> 1, half = grp & 1;
+        const int col = (unit * TPU) * 16 + half * 8;          // LDS column of the main (gate) values
+        float v[8], u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = 0.f; u[j] = 0.f; }
+#pragma unroll
+        for (int wv = 0; wv < TS_WAVES; ++wv) {
+            const float* src = ts_lds + ((size_t)wv * img_rows + img_row) * LDW + col;
+            const floatx4 x = *(const floatx4*)src, y = *(const floatx4*)(src + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += x[j]; v[4 + j] += y[j]; }
+            if (SILU) {
+                const floatx4 p = *(const floatx4*)(src + 16), q = *(const floatx4*)(src + 20);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { u[j] += p[j]; u[4 + j] += q[j]; }
+            }
+        }
+        const int ocol = (u0 + unit) * 16 + half * 8;
+        if (P.splits > 1) {
+            float* dst = P.slab + ((size_t)split * P.m + row) * P.n_out + ocol;
+            *(floatx4*)dst = floatx4{v[0], v[1], v[2], v[3]};
+            *(floatx4*)(dst + 4) = floatx4{v[4], v[5], v[6], v[7]};
+            return;
+        }
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            half_t h = (half_t)v[j];
+            if (SILU) {
+                const float gf = (float)h;
+                const half_t sg = (half_t)(gf / (1.0f + expf(-gf)));
+                h = (half_t)((float)sg * (float)(half_t)u[j]);
+            }
+            o[j] = h;
+        }
+        if (P.out_frag) {      // element (row, ocol + j) -> [ocol / 32][row / 16][(ocol / 8 % 4) * 16 + row % 16][j]
+            const size_t foff = (((size_t)(ocol >> 5) * P.mtp + (row >> 4)) * 64 + ((ocol >> 3) & 3) * 16 + (row & 15)) * 8;
+            *(half8*)(P.out + foff) = o;
+            return;
+        }
+        const size_t off = (size_t)row * P.ldo + ocol;
+        if (!SILU && P.res) {
+            const half8 r = *(const half8*)(P.res + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)o[j] + (float)r[j]);
+        }
+        *(half8*)(P.out + off) = o;
+    };
     for (int m0 = 0; m0 < MT; m0 += MH) {
         if (m0 > 0) __syncthreads();                           // the previous pass has been read out
         float* mine = ts_lds + (size_t)wave * (MH * 16) * LDW;
@@ -172,67 +241,39 @@ __global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) mine[((mt - m0) * 16 + g * 4 + i) * LDW + t * 16 + r16] = acc[mt][t][i];
         __syncthreads();
-        const int row_lo = m0 * 16, row_hi = min(P.m, (m0 + MH) * 16);
+        const int row_lo = m0 * 16, row_hi = min(min(P.m, MT * 16), (m0 + MH) * 16);
         const int items = max(0, row_hi - row_lo) * groups;
-        for (int it = tid; it < items; it += TS_THREADS) {
-            const int row = row_lo + it / groups, grp = it % groups;
-            const int unit = grp >> 1, half = grp & 1;
-            const int col = (unit * TPU) * 16 + half * 8;          // LDS column of the main (gate) values
-            float v[8], u[8];
-    #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[j] = 0.f; u[j] = 0.f; }
-    #pragma unroll
-            for (int wv = 0; wv < TS_WAVES; ++wv) {
-                const float* src = ts_lds + ((size_t)wv * (MH * 16) + (row - row_lo)) * LDW + col;
-                const floatx4 x = *(const floatx4*)src, y = *(const floatx4*)(src + 4);
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] += x[j]; v[4 + j] += y[j]; }
-                if (SILU) {
-                    const floatx4 p = *(const floatx4*)(src + 16), q = *(const floatx4*)(src + 20);
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j) { u[j] += p[j]; u[4 + j] += q[j]; }
-                }
-            }
-            const int ocol = (u0 + unit) * 16 + half * 8;
-            if (P.splits > 1) {
-                float* dst = P.slab + ((size_t)split * P.m + row) * P.n_out + ocol;
-                *(floatx4*)dst = floatx4{v[0], v[1], v[2], v[3]};
-                *(floatx4*)(dst + 4) = floatx4{v[4], v[5], v[6], v[7]};
-                continue;
-            }
-            half8 o;
-    #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                half_t h = (half_t)v[j];
-                if (SILU) {
-                    const float gf = (float)h;
-                    const half_t sg = (half_t)(gf / (1.0f + expf(-gf)));
-                    h = (half_t)((float)sg * (float)(half_t)u[j]);
-                }
-                o[j] = h;
-            }
-            if (P.out_frag) {      // element (row, ocol + j) -> [ocol / 32][row / 16][(ocol / 8 % 4) * 16 + row % 16][j]
-                const size_t foff = (((size_t)(ocol >> 5) * P.mtp + (row >> 4)) * 64 + ((ocol >> 3) & 3) * 16 + (row & 15)) * 8;
-                *(half8*)(P.out + foff) = o;
-                continue;
-            }
-            const size_t off = (size_t)row * P.ldo + ocol;
-            if (!SILU && P.res) {
-                const half8 r = *(const half8*)(P.res + off);
-    #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)o[j] + (float)r[j]);
-            }
-            *(half8*)(P.out + off) = o;
+        for (int it = tid; it < items; it += TS_THREADS) emit(row_lo + it / groups, it / groups, MH * 16, it % groups);
+    }
+    if (TAIL) {
+        // the extra row: the 4 k-groups of a wave meet by lane shuffles, the 4 waves through one-row LDS images
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float x = tacc[t];
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            if (g == 0) ts_lds[(size_t)wave * LDW + t * 16 + r16] = x;
         }
+        __syncthreads();
+        if (MT * 16 < P.m)
+            for (int it = tid; it < groups; it += TS_THREADS) emit(MT * 16, 0, 1, it);
     }
 }
+
+template <int MT, int NT, int D, bool SILU>
+__global__ void __launch_bounds__(TS_THREADS) ts_linear_kernel(const TsParams P) { ts_linear_body<MT, NT, D, SILU, false>(P); }
+
+// 16 MT + 1 activation rows (the kernel name keeps the MFMA row-tile count: <8, ...> runs 129 rows)
+template <int MT, int NT, int D, bool SILU>
+__global__ void __launch_bounds__(TS_THREADS) ts_linear_tail_kernel(const TsParams P) { ts_linear_body<MT, NT, D, SILU, true>(P); }
 
 
 extern "C" size_t sq_linear_ts_workspace_bytes(int m, int n_out, int splits) {
     return splits > 1 ? (size_t)splits * m * n_out * sizeof(float) : 0;
 }
 
-template <int MT, int NT, bool SILU>
+template <int MT, int NT, bool SILU, bool TAIL>
 static void ts_go(const TsParams& P, hipStream_t st) {
     // ring depth: the vmcnt counter tracks 63 loads, so D (NT + MT) must stay below.  Measured on MI355X: deeper
     // rings (up to 8), 8-wave workgroups, and both operands through LDS-DMA (global_load_lds_dwordx4 into a
@@ -241,7 +282,9 @@ static void ts_go(const TsParams& P, hipStream_t st) {
     // not by bytes in flight or by the VGPR return path.
     constexpr int D = (MT * NT > 48) ? 2 : ((MT * NT > 24) ? 3 : 4);     // 8 x 8 accumulator tiles: 256 registers, ring of 2
     const size_t lds = (size_t)TS_WAVES * ts_merge_tiles(MT, NT) * 16 * (NT * 16 + 4) * sizeof(float);
-    auto kern = ts_linear_kernel<MT, NT, D, SILU>;
+    void (*kern)(const TsParams);
+    if constexpr (TAIL) kern = ts_linear_tail_kernel<MT, NT, D, SILU>;
+    else kern = ts_linear_kernel<MT, NT, D, SILU>;
     static bool attr_done[16] = {};          // the attribute is per (function, device)
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -252,27 +295,36 @@ static void ts_go(const TsParams& P, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(P.tiles * P.splits), dim3(TS_THREADS), lds, st, P);
 }
 
-template <int MT>
+template <int MT, bool TAIL = false>
 static int ts_dispatch(const TsParams& P, int silu, int nt, hipStream_t st) {
     if (silu) {
-        if (nt <= 2) ts_go<MT, 2, true>(P, st);
-        else if (nt <= 4) ts_go<MT, 4, true>(P, st);
-        else if (nt <= 6) ts_go<MT, 6, true>(P, st);
+        if (nt <= 2) ts_go<MT, 2, true, TAIL>(P, st);
+        else if (nt <= 4) ts_go<MT, 4, true, TAIL>(P, st);
+        else if (nt <= 6) ts_go<MT, 6, true, TAIL>(P, st);
         else if constexpr (MT <= 8) {                   // 4 gate+up units per workgroup (13B gate_up: 864 units -> 216 workgroups,
-            if (nt <= 8) ts_go<MT, 8, true>(P, st);     // one resident wave of them instead of 288 = 256 + 32)
+            if (nt <= 8) ts_go<MT, 8, true, TAIL>(P, st);     // one resident wave of them instead of 288 = 256 + 32)
             else return SQ_EUNSUPPORTED;
         } else return SQ_EUNSUPPORTED;
         return SQ_OK;
     }
-    if (nt <= 2) ts_go<MT, 2, false>(P, st);
-    else if (nt <= 3) ts_go<MT, 3, false>(P, st);
-    else if (nt <= 4) ts_go<MT, 4, false>(P, st);
-    else if (nt <= 6) ts_go<MT, 6, false>(P, st);
-    else if constexpr (MT <= 8) {                       // 9 x 8 accumulator tiles + a ring of 2 do not fit 512 registers
-        if (nt <= 8) ts_go<MT, 8, false>(P, st);        // (52 spilled VGPRs): 129-144 rows take <= 6 column tiles
+    if (nt <= 2) ts_go<MT, 2, false, TAIL>(P, st);
+    else if (nt <= 3) ts_go<MT, 3, false, TAIL>(P, st);
+    else if (nt <= 4) ts_go<MT, 4, false, TAIL>(P, st);
+    else if (nt <= 6) ts_go<MT, 6, false, TAIL>(P, st);
+    else if constexpr (MT <= 8 && !(TAIL && MT == 8)) { // 9 x 8 accumulator tiles + a ring of 2 do not fit 512 registers
+        if (nt <= 8) ts_go<MT, 8, false, TAIL>(P, st);        // (52 spilled VGPRs): 129-144 rows take <= 6 column tiles; the plain
+        //                                                       8 x 8 + extra-row build spills 5: 129 rows take <= 6 there too
         else return SQ_EUNSUPPORTED;
     } else return SQ_EUNSUPPORTED;
     return SQ_OK;
+}
+
+// 16 MT + 1 rows (65: the 8x8 tree; 129: the 64x2 / 16x8 / ... trees) run the MT-tile kernel with the extra row on the vector
+// ALU (ts_linear_body<.., TAIL>); SEQUOIA_TS_TAIL=0 rounds them up to MT + 1 row tiles as before
+static bool ts_tail_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SEQUOIA_TS_TAIL"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
 }
 
 extern "C" int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const void* res, void* out, int ldo, int out_frag,
@@ -300,7 +352,9 @@ extern "C" int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const vo
     hipStream_t st = (hipStream_t)stream;
     int rc = SQ_OK;
     const int mt = P.mtp;                                    // row tiles; 5 and 7 run on the 6 / 8 builds (tiles alias)
-    if (mt <= 1) rc = ts_dispatch<1>(P, silu, nt, st);
+    if (m == 65 && ts_tail_enabled()) rc = ts_dispatch<4, true>(P, silu, nt, st);
+    else if (m == 129 && ts_tail_enabled()) rc = ts_dispatch<8, true>(P, silu, nt, st);
+    else if (mt <= 1) rc = ts_dispatch<1>(P, silu, nt, st);
     else if (mt == 2) rc = ts_dispatch<2>(P, silu, nt, st);
     else if (mt == 3) rc = ts_dispatch<3>(P, silu, nt, st);
     else if (mt == 4) rc = ts_dispatch<4>(P, silu, nt, st);

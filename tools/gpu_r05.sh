@@ -42,6 +42,20 @@ for stage in "$@"; do
   overlap)     # the forked last draft level: whole-step graphs of the traces whose draft runs the tall-skinny path
     timeout 1200 python -m pytest tests/test_step_pipeline_gpu.py -m gpu -q -k "V32k_seq128 or B_topp09 or D_13b_w4 or E_70b_w2 or L_S256_v32k or config_b or eos" > $O/tests_overlap.log 2>&1
     grep -n "passed\|failed\|rror" $O/tests_overlap.log | tail -8 ;;
+  tslinear)
+    timeout 900 python -m pytest tests/test_ts_linear_gpu.py -m gpu -q > $O/tests_ts_linear.log 2>&1; tail -3 $O/tests_ts_linear.log | cut -c1-300 ;;
+  tunetail)    # launch plans for the 16 MT + 1 row builds: 7B at 65 rows (config C), full-width 70B at 129 rows (config E)
+    rm -f $O/ts_tune_tail.log
+    for shape in qkv "o+res" "gate_up+silu" "down+res"; do
+      TS_ARCH=7b TS_ONLY="$shape" timeout 300 $GRAFT_REPO_ROOT/tools/ts_bench 65 >> $O/ts_tune_tail.log 2>&1
+      TS_ARCH=70b TS_ONLY="$shape" timeout 300 $GRAFT_REPO_ROOT/tools/ts_bench 129 >> $O/ts_tune_tail.log 2>&1
+    done
+    python tools/ts_tune_pick.py $O/ts_tune_tail.log 4
+    SEQUOIA_TS_TAIL=0 TS_ARCH=7b timeout 300 $GRAFT_REPO_ROOT/tools/ts_bench 65 > $O/ts_tune_notail_7b_65.log 2>&1
+    python tools/ts_tune_pick.py $O/ts_tune_notail_7b_65.log 2 ;;
+  tailtraces)
+    timeout 1500 python -m pytest tests/test_e2e_gpu.py tests/test_step_pipeline_gpu.py tests/test_tp_native_gpu.py -m gpu -q -k "C_7b or E_70b_w2 or native" > $O/tests_tail_traces.log 2>&1
+    grep -n "passed\|failed\|rror" $O/tests_tail_traces.log | tail -6 | cut -c1-300 ;;
   tune70b)     # launch plans of the full-width 70B projections at 129 rows (configuration E at TP = 1): every (tiles, splits) candidate
     for shape in qkv "o+res" "gate_up+silu" "down+res"; do
       TS_ARCH=70b TS_ONLY="$shape" timeout 300 $GRAFT_REPO_ROOT/tools/ts_bench 129 >> $O/ts_tune_70b_129rows.log 2>&1
