@@ -81,7 +81,8 @@ def candidates(n_out: int, k: int, silu: bool, m: int, allow_split: bool = False
                 out.append((tiles, splits))
     wide = 6 if m > 64 else 4
     if silu:
-        add(n_out // 16, 4 if m <= 128 else 3, (1,))         # fused epilogue: <= 4 gate+up units (8 MFMA column tiles; 3 beyond 128 rows)
+        add(n_out // 16, 4 if m <= 129 else 3, (1,))         # fused epilogue: <= 4 gate+up units (8 MFMA column tiles; 3 beyond 129 rows:
+        #                                                      129 = 8 MFMA row tiles + the extra row on the vector ALU, csrc/ts_linear.hip)
         if allow_split:
             add(2 * n_out // 16, wide, (2, 3, 4))
     else:

@@ -59,10 +59,10 @@ constexpr int ts_merge_tiles(int mt, int nt) {
     return fit >= mt ? mt : fit;
 }
 
-// TAIL: the activation block has 16 MT + 1 rows -- a tree of 2^k-ary levels plus its root: the 65-node 8x8 tree, the
-// 129-node 64x2 / 16x8 / ... trees of the reference's growmaps.  Rounding 129 rows up to 9 MFMA row tiles costs an eighth more
-// activation ingest and MFMA work and, above all, accumulator registers (9 x 8 tiles do not fit: <= 6 column tiles per
-// workgroup); 65 rows ran on the 6-tile build.  Here the 16 MT full tiles go through the MFMAs and the ONE extra row rides
+// TAIL: the activation block has 16 MT + 1 rows -- a tree of 2^k-ary levels plus its root: the 129-node 64x2 / 16x8 / 128x1
+// trees of the reference's growmaps.  Rounding 129 rows up to 9 MFMA row tiles costs an eighth more activation ingest and
+// MFMA work and, above all, accumulator registers (9 x 8 tiles do not fit: <= 6 column tiles per workgroup).  Here the 16 MT
+// full tiles go through the MFMAs and the ONE extra row rides
 // beside them on the vector ALU: its 8 k-values of the lane's k-group (a 16-byte broadcast load from tile MT of the
 // fragment-major image, row 0) are multiplied into the weight fragment the lane holds anyway -- 4 v_dot2c_f32_f16 per column
 // tile and k-step, on the otherwise idle VALU -- and the 4 k-groups' partial dots meet by two lane shuffles at the end.
@@ -319,8 +319,9 @@ static int ts_dispatch(const TsParams& P, int silu, int nt, hipStream_t st) {
     return SQ_OK;
 }
 
-// 16 MT + 1 rows (65: the 8x8 tree; 129: the 64x2 / 16x8 / ... trees) run the MT-tile kernel with the extra row on the vector
-// ALU (ts_linear_body<.., TAIL>); SEQUOIA_TS_TAIL=0 rounds them up to MT + 1 row tiles as before
+// 129 rows (the 64x2 / 16x8 / 128x1 ... trees: 128 nodes + the root) run the 8-tile kernel with the extra row on the vector ALU
+// (ts_linear_body<.., TAIL>): what it buys is the 8-column-tile SwiGLU workgroup the 9-tile build has no registers for
+// (70B gate_up at 129 rows: 249 -> 224 us); SEQUOIA_TS_TAIL=0 rounds 129 up to 9 row tiles as before
 static bool ts_tail_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("SEQUOIA_TS_TAIL"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -352,8 +353,8 @@ extern "C" int sq_linear_ts_f16(const void* a_frag, const void* w_frag, const vo
     hipStream_t st = (hipStream_t)stream;
     int rc = SQ_OK;
     const int mt = P.mtp;                                    // row tiles; 5 and 7 run on the 6 / 8 builds (tiles alias)
-    if (m == 65 && ts_tail_enabled()) rc = ts_dispatch<4, true>(P, silu, nt, st);
-    else if (m == 129 && ts_tail_enabled()) rc = ts_dispatch<8, true>(P, silu, nt, st);
+    // (65 rows -- 4 tiles + 1 -- measured equal on the 6-tile build, whose aliased tiles hit L1: not routed here)
+    if (m == 129 && ts_tail_enabled()) rc = ts_dispatch<8, true>(P, silu, nt, st);
     else if (mt <= 1) rc = ts_dispatch<1>(P, silu, nt, st);
     else if (mt == 2) rc = ts_dispatch<2>(P, silu, nt, st);
     else if (mt == 3) rc = ts_dispatch<3>(P, silu, nt, st);

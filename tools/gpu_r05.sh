@@ -42,6 +42,9 @@ for stage in "$@"; do
   overlap)     # the forked last draft level: whole-step graphs of the traces whose draft runs the tall-skinny path
     timeout 1200 python -m pytest tests/test_step_pipeline_gpu.py -m gpu -q -k "V32k_seq128 or B_topp09 or D_13b_w4 or E_70b_w2 or L_S256_v32k or config_b or eos" > $O/tests_overlap.log 2>&1
     grep -n "passed\|failed\|rror" $O/tests_overlap.log | tail -8 ;;
+  pmc_ts)      # FETCH / WRITE / MFMA passes of the projection kernel at the shipped plans + tree attention -> profiles/r05_pmc.json
+    bash tools/pmc_r05.sh > $O/pmc_ts_run.log 2>&1; tail -14 $O/pmc_ts_run.log
+    [ -f gpurun_out/r05/pmc_ts/r05_pmc.json ] && cp gpurun_out/r05/pmc_ts/r05_pmc.json $O/pmc.json && cp $O/pmc.json profiles/r05_pmc.json ;;
   tslinear)
     timeout 900 python -m pytest tests/test_ts_linear_gpu.py -m gpu -q > $O/tests_ts_linear.log 2>&1; tail -3 $O/tests_ts_linear.log | cut -c1-300 ;;
   tunetail)    # launch plans for the 16 MT + 1 row builds: 7B at 65 rows (config C), full-width 70B at 129 rows (config E)
