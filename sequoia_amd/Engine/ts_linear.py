@@ -236,6 +236,14 @@ class TsLinearSet:
                 if rec != "torch" and int(rec[1]) > SPLITS_CAP.get(name, 1):
                     raise ValueError(f"launch plan {plan_key(n_out, k, silu, mtp)} = {rec}: {name} takes at most "
                                      f"{SPLITS_CAP.get(name, 1)} K-splits (the split-K slab buffer is sized for that)")
+                if rec != "torch":
+                    # a plan is keyed by ROW TILES (ceil(q / 16)), the kernel's register budget by rows: 129 rows run the
+                    # 8-tile + extra-row build (<= 8 SwiGLU column tiles, <= 6 plain), 130-144 rows the 9-tile build (<= 6 / <= 6)
+                    # -- a plan measured at 129 rows must still launch for a 144-row chunk of a prefill
+                    units = n_out // 16
+                    max_u = (4 if q_len <= 129 else 3) if silu else (8 if q_len <= 128 else 6)
+                    if int(rec[1]) == 1 and -(-units // int(rec[0])) > max_u:
+                        rec = (-(-units // max_u), 1)
                 p[name] = None if rec == "torch" else (int(rec[0]), int(rec[1]))
             if not capturing:
                 for name, v in p.items():                   # materialise the weight images now, outside any capture
