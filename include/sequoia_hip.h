@@ -344,11 +344,13 @@ int sq_silu_mul_f16(const void* gate_up, void* out, int rows, int inter, void* s
 int sq_repack_linear_weight_f16(const void* w, void* w_frag, int n, int k, void* stream);
 int sq_repack_rows_frag_f16(const void* x, int ldx, void* x_frag, int m, int k, void* stream);
 
-/* Tall-skinny linear layer of a tree forward (m <= 128 rows: one tree / tree level), nn.Linear semantics
+/* Tall-skinny linear layer of a tree forward (m <= 144 rows: one tree / tree level), nn.Linear semantics
  * out = a . w^T, fp32 accumulation, fp16 output -- the dense projections of LlamaAttention_FI/TG and LlamaMLP_FI
  * (Engine/Llama_modules.py:104-112,138,199-207,256,262-271) when q_len <= 144, as an HBM weight stream over
  * fragment-major operands (above).  The launch has tiles x splits workgroups: the n_out / 16 column units are
- * partitioned over `tiles` workgroups (<= 4 units each; silu: <= 3), K over `splits`.
+ * partitioned over `tiles` workgroups, K over `splits`.  Units per workgroup (SQ_EUNSUPPORTED beyond): plain <= 8 up to
+ * 128 rows, <= 6 for 129-144; silu (gate+up pairs) <= 4 up to 129 rows, <= 3 for 130-144.  m == 129 (a 128-node tree and
+ * its root) runs 8 MFMA row tiles with the extra row on the vector ALU instead of 9 row tiles (csrc/ts_linear.hip).
  *   splits == 1, silu != 0   : w_frag holds gate tiles [0, n_out/16) then up tiles;
  *                              out = h(h(silu(h(g))) * h(u))                                         (:271)
  *   splits == 1, res != NULL : out = h(h(acc) + res) (fp16 add, the decoder layer's skip connection
