@@ -113,10 +113,10 @@ def run_other_config(name, args, device, prompts, engines=None, steps=20, warmup
             del loop2
         except Exception as e:
             out["mi355x_growmap"] = dict(error=f"{type(e).__name__}: {e}")
-    if name == "D":
+    if name in ("D", "E"):
         pk = None
         if dom.startswith("linear_ts_") and d.get("plan"):
-            pk = f"D:{dom[len('linear_ts_'):]}@{(gm.size + 15) // 16}:{d['plan'][0]}x{d['plan'][1]}"
+            pk = f"{name}:{dom[len('linear_ts_'):]}@{(gm.size + 15) // 16}:{d['plan'][0]}x{d['plan'][1]}"
             traffic, mfma_util, pmc_file, note = pmc_lookup(pk, dom)
             out["roofline"].update(traffic=traffic, mfma_util=mfma_util, pmc_key=pk, pmc_file=pmc_file)
             if note:

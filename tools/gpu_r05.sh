@@ -45,6 +45,10 @@ for stage in "$@"; do
   pmc_ts)      # FETCH / WRITE / MFMA passes of the projection kernel at the shipped plans + tree attention -> profiles/r05_pmc.json
     bash tools/pmc_r05.sh > $O/pmc_ts_run.log 2>&1; tail -14 $O/pmc_ts_run.log
     [ -f gpurun_out/r05/pmc_ts/r05_pmc.json ] && cp gpurun_out/r05/pmc_ts/r05_pmc.json $O/pmc.json && cp $O/pmc.json profiles/r05_pmc.json ;;
+  loopE)       # rocprofv3 --kernel-trace --stats of configuration E's loop (TP = 1)
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_loopE -o b -- python $GRAFT_REPO_ROOT/bench.py --config E --steps 24 --warmup 4 --no-kernel-rooflines --no-cpu-baseline --no-tuned-growmap --no-autoregressive --no-other-configs --no-reference-metric > $O/prof_loopE.log 2>&1)
+    python tools/rocprof_summary.py $(find $O/prof_loopE -name "*results.db" | head -1) 30 > $O/kernel_stats_loop_configE.md; find $O/prof_loopE -name "*.db" -delete
+    head -22 $O/kernel_stats_loop_configE.md | cut -c1-150 ;;
   tslinear)
     timeout 900 python -m pytest tests/test_ts_linear_gpu.py -m gpu -q > $O/tests_ts_linear.log 2>&1; tail -3 $O/tests_ts_linear.log | cut -c1-300 ;;
   tunetail)    # launch plans for the 16 MT + 1 row builds: 7B at 65 rows (config C), full-width 70B at 129 rows (config E)

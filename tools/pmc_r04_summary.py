@@ -67,6 +67,12 @@ add("D:gate_up@4:216x1", "ts_d_gate_up", "ts_linear_kernel<4, 8, 3, true>", 5529
     2 * 13824 * 5120 * 2 + R * 5120 * 2 + R * 13824 * 2)
 add("D:down@4:80x3", "ts_d_down", "ts_linear_kernel<4, 4, 4, false>", 61440, "13B down_proj 5120x13824, 64 rows, tiles 80 x splits 3 (pair-tuned with its norm)",
     5120 * 13824 * 2 + R * 13824 * 2 + 3 * R * 5120 * 4)
+# configuration E at TP = 1 (round 5): full-width Llama-2-70b projections at the 129 rows of the 64x2 tree
+R9 = 129
+add("E:gate_up@9:448x1", "ts_e_gate_up", "ts_linear_tail_kernel<8, 8, 2, true>", 114688, "70B gate_up 2x28672x8192 + SwiGLU, 129 rows, tiles 448 (8 MFMA row tiles + the extra row on the vector ALU, 4 gate+up units / workgroup)",
+    2 * 28672 * 8192 * 2 + R9 * 8192 * 2 + R9 * 28672 * 2)
+add("E:down@9:128x4", "ts_e_down", "ts_linear_tail_kernel<8, 4, 3, false>", 131072, "70B down_proj 8192x28672, 129 rows, tiles 128 x splits 4",
+    8192 * 28672 * 2 + R9 * 28672 * 2 + 4 * R9 * 8192 * 4)
 add("tree_attention_target7b", "attn", "tree_attention_kernel<128, 1>", 131072, "7B verify layer: H=32, q=128, kv_len=287, D=128, implicit tree mask",
     2 * 32 * 287 * 128 * 2 + 2 * 32 * 128 * 128 * 2)
 add("tree_attention_draft68m_level", "attn", "tree_attention_kernel<64, 1>", 24576, "68m draft level: H=12, q=34, kv_len=214, D=64",

@@ -21,6 +21,9 @@ run_ts d_qkv 13b 64 qkv 120 2
 run_ts d_o 13b 64 "o+res" 80 3
 run_ts d_gate_up 13b 64 "gate_up+silu" 216 1
 run_ts d_down 13b 64 "down+res" 80 3
+# configuration E at TP = 1: the full-width 70B gate_up at 129 rows on the 8-tile + extra-row build (4 units per workgroup)
+run_ts e_gate_up 70b 129 "gate_up+silu" 448 1
+run_ts e_down 70b 129 "down+res" 128 4
 for pass in "${PASSES[@]}"; do
   tagp=$(echo $pass | cut -d' ' -f1)
   timeout 300 rocprofv3 --kernel-trace --pmc $pass -d $OUT/attn_$tagp -o r -- python $GRAFT_REPO_ROOT/tools/kbench.py attn > $OUT/attn_$tagp.log 2>&1
