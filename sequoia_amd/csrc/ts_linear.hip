@@ -74,7 +74,14 @@ __device__ __forceinline__ void ts_linear_body(const TsParams& P) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: K ranges and loop bounds stay scalar
     const int r16 = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x % P.tiles, split = blockIdx.x / P.tiles;
+    // Block -> (column tile, K split).  Block b runs on XCD b % 8 (observed placement, used for speed only), and each XCD has its
+    // own L2: with 2 / 4 / 8 K-splits the split is b % splits, so every XCD works on ONE K range and its L2 holds only that
+    // 1 / splits slice of the activation image (7B down_proj: 0.7 MB instead of the whole 2.8 MB image per XCD -- PMC showed the
+    // image re-fetched once per XCD: o / down 1.20-1.22x, the 70B down_proj 1.34x of the algorithmic bytes).  Other split counts
+    // keep the tile-minor order.  The work per (tile, split) and its result are the same either way.
+    const bool split_minor = P.splits == 2 || P.splits == 4 || P.splits == 8;
+    const int tile = split_minor ? (int)(blockIdx.x / P.splits) : (int)(blockIdx.x % P.tiles);
+    const int split = split_minor ? (int)(blockIdx.x % P.splits) : (int)(blockIdx.x / P.tiles);
     const int u0 = (int)((long)tile * P.units / P.tiles), u1 = (int)((long)(tile + 1) * P.units / P.tiles);
     const int nu = u1 - u0;                                  // 16-column units of this workgroup (<= NT / TPU)
 

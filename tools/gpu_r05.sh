@@ -45,6 +45,11 @@ for stage in "$@"; do
   pmc_ts)      # FETCH / WRITE / MFMA passes of the projection kernel at the shipped plans + tree attention -> profiles/r05_pmc.json
     bash tools/pmc_r05.sh > $O/pmc_ts_run.log 2>&1; tail -14 $O/pmc_ts_run.log
     [ -f gpurun_out/r05/pmc_ts/r05_pmc.json ] && cp gpurun_out/r05/pmc_ts/r05_pmc.json $O/pmc.json && cp $O/pmc.json profiles/r05_pmc.json ;;
+  tsplans)     # the shipped 128-row 7B plans and the 129-row 70B plans, standalone (tools/ts_bench)
+    for spec in "7b:128:qkv:128:2" "7b:128:o+res:64:4" "7b:128:gate_up+silu:230:1" "7b:128:down+res:64:4" "7b:128:o+res:128:2" "7b:128:down+res:128:2" "7b:128:down+res:32:8" "70b:129:qkv:128:2" "70b:129:o+res:128:2" "70b:129:down+res:128:4" "70b:129:down+res:64:8" "13b:64:qkv:120:2"; do
+      IFS=: read arch rows shape tiles splits <<< "$spec"
+      TS_ARCH=$arch TS_ONLY="$shape" TS_TILES=$tiles TS_SPLITS=$splits timeout 200 $GRAFT_REPO_ROOT/tools/ts_bench $rows 2>&1 | grep "us "
+    done ;;
   loopE)       # rocprofv3 --kernel-trace --stats of configuration E's loop (TP = 1)
     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_loopE -o b -- python $GRAFT_REPO_ROOT/bench.py --config E --steps 24 --warmup 4 --no-kernel-rooflines --no-cpu-baseline --no-tuned-growmap --no-autoregressive --no-other-configs --no-reference-metric > $O/prof_loopE.log 2>&1)
     python tools/rocprof_summary.py $(find $O/prof_loopE -name "*results.db" | head -1) 30 > $O/kernel_stats_loop_configE.md; find $O/prof_loopE -name "*.db" -delete
