@@ -183,3 +183,35 @@ def test_lossless_commit_order_replay_matches_oracle(name):
             break
     assert tree.quirk_steps == 0
     print(f"{name}: lossless replay == oracle in every step; {quirk_candidates} step(s) where the reference order would differ")
+
+
+@pytest.mark.parametrize("arch,rows", [("JackFram/llama-68m", 34), ("princeton-nlp/Sheared-LLaMA-1.3B", 13)])
+def test_kv_only_forward_writes_the_full_forward_kv_rows(arch, rows):
+    """The draft forward over the last tree level needs only its KV rows (TreeContext.need_logits = False: the forward stops after
+    its last layer's RoPE + KV write and returns None).  Every K / V row of every layer must equal, bit for bit, what the full
+    forward writes -- they are what the next step's context is built from when a leaf is accepted."""
+    from sequoia_amd.Engine.Engine import GraphInferenceEngine
+    from sequoia_amd.Engine.Llama_modules import TreeContext
+    from sequoia_amd.growmap import GrowMap
+    M = 384
+    eng = GraphInferenceEngine(max_length=M, model_name_or_path=f"random:{arch}:seed=5:gain=20", dtype=torch.float16, device=DEV)
+    assert eng.engine.model.ts is not None
+    g = GrowMap.load("A100-CNN-68m-7b-stochastic")
+    bm = g.device_tensors(DEV)["bitmask"]
+    torch.manual_seed(1)
+    n0 = 126
+    ids = torch.randint(3, 32000, (1, n0 + rows), device=DEV)
+    pos = torch.arange(n0 + rows, device=DEV)
+    caches = []
+    for need in (True, False):
+        eng.clear_kv()
+        eng.inference(input_ids=ids[:, :n0], storage_ids=pos[:n0], position_ids=pos[None, :n0], attn_mask=None,
+                      tree=TreeContext(0, n0, g.size, bm, n0))
+        ctx = TreeContext(n0, n0, g.size, bm, n0 + rows, contiguous_slots=True, need_logits=need)
+        out = eng.inference(input_ids=ids[:, n0:], storage_ids=pos[n0:], position_ids=pos[None, n0:], attn_mask=None, tree=ctx)
+        assert (out is None) == (not need)
+        assert eng.engine.kv_cache.kv_offset == n0 + rows
+        kc = eng.engine.kv_cache
+        caches.append((kc.k_cache[..., :n0 + rows, :].clone(), kc.v_cache[..., :n0 + rows, :].clone()))
+    assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1], caches[1][1])
+    assert caches[0][0][..., n0:, :].abs().sum() > 0

@@ -75,6 +75,8 @@ for stage in "$@"; do
     python tools/ts_tune_pick.py $O/ts_tune_70b_129rows.log ;;
   xgmi)
     timeout 1500 python -m pytest tests/test_xgmi_allreduce_gpu.py -m gpu -q > $O/tests_xgmi.log 2>&1; tail -3 $O/tests_xgmi.log | cut -c1-300 ;;
+  kvonly)
+    timeout 600 python -m pytest tests/test_e2e_gpu.py -m gpu -q -k "kv_only" > $O/tests_kvonly.log 2>&1; tail -3 $O/tests_kvonly.log | cut -c1-300 ;;
   lossless)
     timeout 900 python -m pytest tests/test_e2e_gpu.py -m gpu -q -k "lossless" > $O/tests_lossless.log 2>&1; tail -3 $O/tests_lossless.log | cut -c1-300 ;;
   kernels)
