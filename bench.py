@@ -149,6 +149,7 @@ def main():
     value_steady = (new_tok - prefill_tok) / max(secs - prefill_secs, 1e-9)
     rccl_ranks = 1
     allreduce = None
+    secs_local = secs
     if world > 1:
         dist.barrier()
         if tp_mode:
@@ -158,8 +159,11 @@ def main():
         if tp_mode:                    # all ranks produced the SAME tokens: count them once
             steps_all = steps
         else:
-            c = torch.tensor([float(new_tok), float(steps)], device=device); dist.all_reduce(c)
+            c = torch.tensor([float(new_tok), float(steps), float(new_tok - prefill_tok)], device=device); dist.all_reduce(c)
             new_tok, steps_all = float(c[0]), float(c[1])
+            # `value_steady` is whole-job like `value`: steady tokens of all replicas over the slowest replica's steady time
+            st = torch.tensor([secs_local - prefill_secs], device=device); dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            value_steady = float(c[2]) / max(float(st), 1e-9)
     else:
         steps_all = steps
 
