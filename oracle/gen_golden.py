@@ -521,6 +521,13 @@ def main_live(specs, out_dir):
             run_case(R, f"live_v32k_{seed}", gm("A100_growmaps/68m_7b/growmaps/A100-CNN-68m-7b-stochastic.pt"), (768, 3072, 2, 12, 12),
                      (768, 3072, 12, 12, 12), 32000, 384, 0.6, "stochastic", 32, 3, seed, logit_gain=10.0, seeded=True,
                      share_vocab=0.05, compact=16, branch_scale=0.005, out_dir=out_dir)
+        elif mode in ("s256", "s512", "l8x24"):
+            # the reference's large growmaps (256 / 512 / 193 nodes), tiny dims, full op logs (a temporary directory: size is no issue)
+            path, M_, plen, steps_ = {"s256": ("A100_growmaps/68m_13b/growmaps/A100-CNN-68m-13b-stochastic-S256.pt", 512, 24, 2),
+                                      "s512": ("A100_growmaps/68m_13b/growmaps/A100-CNN-68m-13b-stochastic-S512.pt", 768, 16, 2),
+                                      "l8x24": ("L40_growmaps/8x24-tree.pt", 512, 20, 2)}[mode]
+            run_case(R, f"live_{mode}_{seed}", gm(path), tiny, tiny, 1024, M_, 0.6, "stochastic", plen, steps_, seed,
+                     logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
         elif mode in ("spectest", "greedytest"):
             run_probe_case(R, f"live_{mode}_{seed}", mode, tiny, 1024, 128, 0.6, 8, 16, 10, seed, noise=0.6, out_dir=out_dir)
         else:

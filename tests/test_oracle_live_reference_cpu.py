@@ -122,6 +122,9 @@ LIVE_SPECS = ["live:stochastic:301", "live:stochastic:302", "live:sequoia128:303
               "live:topp:310"]     # (+ SpecTree under the harness's default nucleus filter top_p = 0.9)
 BASELINE_SPECS = ["live:specinfer:305", "live:greedys:306"]          # the paper's comparison baselines
 PROBE_SPECS = ["live:spectest:307", "live:greedytest:308"]           # the acceptance-rate probes
+# the reference's large growmaps (256 / 512 / 193 nodes) on fresh seeds: checked op by op on the oracle (the reference's own inputs,
+# so no decision margin is involved); the host-loop replay of such trees is pinned on the committed, margin-screened L_* traces
+LARGE_SPECS = ["live:s256:311", "live:s512:312", "live:l8x24:313"]
 VOCAB_SPECS = ["live:v32k:309"]            # the real vocabulary: 68m-dims -> 160m-dims, config B's growmap, seeded weights, compact logits
 
 
@@ -135,18 +138,18 @@ def live_traces(tmp_path_factory):
     out = tmp_path_factory.mktemp("live_traces")
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SEQUOIA_GOLDEN_OUT=str(out))
-    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py")] + LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS + VOCAB_SPECS, env=env, cwd=repo,
+    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py")] + LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS + VOCAB_SPECS + LARGE_SPECS, env=env, cwd=repo,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     traces = {}
-    for spec in LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS + VOCAB_SPECS:
+    for spec in LIVE_SPECS + BASELINE_SPECS + PROBE_SPECS + VOCAB_SPECS + LARGE_SPECS:
         _, mode, seed = spec.split(":")
         z = np.load(os.path.join(str(out), f"trace_live_{mode}_{seed}.npz"))
         traces[spec] = (z, json.loads(bytes(z["meta_json"]).decode()))
     return traces
 
 
-@pytest.mark.parametrize("spec", LIVE_SPECS)
+@pytest.mark.parametrize("spec", LIVE_SPECS + LARGE_SPECS)
 def test_live_trace_sampler_and_verifier_on_the_oracle(live_traces, spec):
     """Every sampler call and every verification of a fresh reference run, op by op on the oracle (the checks of
     tests/test_oracle_golden.py::test_sampler_matches_reference / test_verify_*_matches_reference)."""
