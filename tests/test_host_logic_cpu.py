@@ -134,6 +134,16 @@ def test_loop_run_prompts_counts_whole_prompts_and_prefill_steps():
         secs, toks, steps = loop.run_prompts(2)
         assert loop.prompts_done == 2 and loop.prefill_steps == 3 and loop.tree is None
         assert steps >= 2 and toks >= 2 * 12 and 0 < loop.prefill_seconds <= secs + 1.0
+        # bench.py's timed window: start_fresh_prompt() drops a half-done prompt, so the next K steps begin with a
+        # prefill-bearing step whose time and tokens are accounted apart (`value` vs `value_steady`)
+        loop.run_steps(1)
+        assert loop.tree is not None
+        loop.start_fresh_prompt()
+        assert loop.tree is None
+        p0, s0, t0 = loop.prefill_steps, loop.prefill_seconds, loop.prefill_tokens
+        secs, toks, steps = loop.run_steps(3)
+        assert steps == 3 and loop.prefill_steps - p0 == 1 and loop.prefill_seconds > s0
+        assert 1 <= loop.prefill_tokens - t0 <= toks
     finally:
         ops.set_ops_for_testing(None)
 
