@@ -570,9 +570,11 @@ def main():
     run_case(R, "E_64x2", gm("L40_growmaps/64x2-tree.pt"), tiny, gqa_t, 1024, 224, 0.6, "stochastic", 16, 2, 21,
              logit_gain=6.0, out_dir=out_dir)
     # the paper's comparison baselines on the same harness
-    run_case(R, "F_specinfer", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "specinfer", 20, 4, 22,
+    # (round 5: seeds screened like the large-tree traces -- 64 inverse-CDF draws per step sit on a CDF boundary within the
+    # GPU's logit distance for about four seeds in five; rounds 3-4 carried seeds 22 / 23 with one PROVEN input-limited draw each)
+    run_case(R, "F_specinfer", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "specinfer", 20, 4, 83,
              logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
-    run_case(R, "G_greedys", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "greedys", 20, 4, 23,
+    run_case(R, "G_greedys", gm("L40_growmaps/8x8-tree.pt"), tiny, tiny, 1024, 192, 0.6, "greedys", 20, 4, 91,
              logit_gain=8.0, share_weights=0.05, out_dir=out_dir)
     # config D: the 64-node 160m->13b growmap (levels 12/18/20/13); target with 5 heads of D = 128 like Llama-2-13b's
     # 40 = 5 x 8 (an odd multiple); weights seeded, not stored

@@ -29,17 +29,16 @@ def pytest_sessionstart(session):
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
-    """How many margin-limited decisions the session ACCEPTED (tests/helpers.py::ESCAPES).  The committed SpecTree /
-    GreedyTree fixtures are fail-closed, so every entry comes from fresh random inputs, live traces, or the two baseline
-    traces whose inverse-CDF draws are proven input-limited (helpers.KNOWN_INPUT_LIMITED)."""
+    """How many margin-limited decisions the session ACCEPTED (tests/helpers.py::ESCAPES).  Every committed fixture is
+    fail-closed (helpers.KNOWN_INPUT_LIMITED is empty since round 5), so every entry comes from fresh random inputs or live
+    traces of the reference on new seeds."""
     try:
         import helpers
     except Exception:
         return
     esc = helpers.ESCAPES
-    terminalreporter.write_line(f"margin-limited decisions accepted: {len(esc)} (committed SpecTree / GreedyTree fixtures are fail-closed: "
-                                "entries come from fresh random inputs, live traces, or the proven input-limited inverse-CDF "
-                                "draws of the baseline traces F_specinfer / G_greedys)")
+    terminalreporter.write_line(f"margin-limited decisions accepted: {len(esc)} (every committed fixture is fail-closed: entries come "
+                                "from fresh random inputs or live traces of the reference on new seeds)")
     for label, m in esc:
         terminalreporter.write_line(f"  {label}: margin {m:.3e}")
     if helpers.LOGIT_EXCESS:

@@ -80,6 +80,8 @@ for stage in "$@"; do
   replicas2)   # the driver's N > 1 command with two replica ranks on the one GPU (gloo), incl. the tensor-parallel child job
     SEQUOIA_BENCH_ONE_DEVICE=1 timeout 1200 python bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_replicas2.json 2> $O/bench_replicas2.err; line $O/bench_replicas2.json; python -c "
 import json;d=json.loads(open('$O/bench_replicas2.json').read().strip().splitlines()[-1]);t=d.get('tp_70b') or {};print('n_gpus',d.get('n_gpus'),'rccl_ranks',d.get('rccl_ranks'),'tp_70b',{k:t.get(k) for k in ('value','ms_per_step','allreduce_kind','xgmi_status','error','steady_ms_per_step')})" ;;
+  baselines)
+    timeout 900 python -m pytest tests/test_baselines_gpu.py tests/test_properties_gpu.py -m gpu -q > $O/tests_baselines.log 2>&1; tail -6 $O/tests_baselines.log | cut -c1-300 ;;
   kvonly)
     timeout 600 python -m pytest tests/test_e2e_gpu.py -m gpu -q -k "kv_only" > $O/tests_kvonly.log 2>&1; tail -3 $O/tests_kvonly.log | cut -c1-300 ;;
   lossless)
