@@ -477,6 +477,27 @@ int sq_norm_linear_f16(const void* x, const int64_t* d_ids, const void* embed, i
                        const void* norm_weight, float eps, const void* w_frag, void* out, int ldo, int m, int n_out,
                        int k, int swiglu, int tiles, void* stream);
 
+/* ---- f1: the attention half of a small draft model's decoder layer in ONE launch ---------------------------------
+ * For forwards whose rows never attend to each other -- the draft forward over ONE tree level (Tree/SpecTree.py:87-134:
+ * the new nodes of a level are siblings / cousins, none is another's ancestor) and any one-row forward -- of a model with
+ * heads of 64 and hidden in {512, 768, 1024} (JackFram/llama-68m / -160m).  One workgroup per (head, 16-row tile) runs
+ *   q | k | v = a . Wqkv[head]^T  ->  RoPE (fp16 rounding per op, Engine/offload_engine.py:63-66)  ->  K / V rows into the
+ *   cache slots d_storage_ids (Engine/Llama_KV.py:72-89)  ->  tree attention over the cached keys [0, q_slot0) plus the
+ *   row's own key  ->  the head's slice of o_proj as an fp32 partial slab[head][row][hidden],
+ * i.e. LlamaAttention_FI.forward (Engine/Llama_modules.py:87-140) without its four kernel boundaries; the residual add +
+ * RMSNorm that follows sums the head partials in head order (sq_add_rmsnorm_slabs_f16 with splits = n_heads).  Rounding
+ * points are those of sq_linear_ts_f16 + sq_rope_kv_write_f16 + sq_tree_attention_f16; fp32 summation orders differ.
+ * a_frag: fragment-major image of the normalised input rows (sq_rmsnorm_frag_f16 ...); wqkv_frag / wo_frag:
+ * sq_repack_linear_weight_f16 images of the packed q|k|v weight [(3 H 64)][hidden] and of o_proj [hidden][H 64].
+ * The caller guarantees: query i sits at slot q_slot0 + i, and no query may see another query's key (only its own).
+ * Mask rule for the cached keys: as sq_tree_attention_f16 (mask_mode 1); d_ctx optionally overrides {q_slot0, gt}.
+ * kv_only != 0: stop after the K / V rows are written (wo_frag / slab unused).                                        */
+int sq_draft_attn_block_f16(const void* a_frag, const void* wqkv_frag, const void* wo_frag, float* slab, size_t slab_bytes,
+                            void* k_layer, void* v_layer, const void* cos_tab, const void* sin_tab,
+                            const int64_t* d_position_ids, const int64_t* d_storage_ids, int q_len, int n_heads, int d,
+                            int hidden, int m, float scale, int q_slot0, int gt, int n_tree, const uint64_t* d_bitmask,
+                            int words, const int32_t* d_ctx, int kv_only, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,7 +106,7 @@ class _GraphRunner:
     the reference's capture_graph closure, Engine/Engine.py:127-166)."""
 
     def __init__(self, engine: InferenceEngine, q_len: int, mempool, n_warmups: int, mode: str, n_tree: int = 1,
-                 bitmask=None):
+                 bitmask=None, independent_rows: bool = False):
         dev, M = engine.device, engine.max_length
         prime_graph_rng(dev)
         self.engine, self.q_len, self.mode = engine, q_len, mode
@@ -120,7 +120,7 @@ class _GraphRunner:
         else:
             self.ctx = torch.tensor([0, 1, q_len], dtype=torch.int32, device=dev)
             self.tree = TreeContext(q_slot0=0, gt=1, n_tree=n_tree, bitmask=bitmask, kv_len=q_len, ctx=self.ctx,
-                                    contiguous_slots=True)
+                                    contiguous_slots=True, independent_rows=independent_rows)
         kv = engine.kv_cache
         saved = (kv.kv_offset, kv.dirty_end)
         s = torch.cuda.Stream()
@@ -207,6 +207,14 @@ class GraphInferenceEngine:
                 if key not in self.tree_callables:
                     self.tree_callables[key] = _GraphRunner(self.engine, q_len, self.mempool, n_warmups, "tree",
                                                             n_tree=n_tree, bitmask=tree_bitmask)
+                    # a second capture for forwards whose rows never see each other (one tree level): small drafts run
+                    # the attention half of a layer as one launch there (Engine/ts_linear.py::attn_block_ok)
+                    from .ts_linear import block_capable
+                    model = getattr(self.engine, "model", None)
+                    if q_len > 1 and model is not None and block_capable(model, q_len):
+                        self.tree_callables[key + ("independent",)] = _GraphRunner(
+                            self.engine, q_len, self.mempool, n_warmups, "tree", n_tree=n_tree, bitmask=tree_bitmask,
+                            independent_rows=True)
         if clear_kv:
             self.engine.clear_kv()
 
@@ -246,7 +254,11 @@ class GraphInferenceEngine:
                 assert attn_mask.shape[2] == dec_length and attn_mask.shape[3] == self.engine.max_length
         if tree is not None:
             # the captured forwards assume storage_ids == q_slot0 + arange(q_len) (fused RoPE + attention)
-            runner = self.tree_callables.get((dec_length, tree.bitmask.data_ptr())) if tree.contiguous_slots else None
+            runner = None
+            if tree.contiguous_slots:
+                key = (dec_length, tree.bitmask.data_ptr())
+                runner = (self.tree_callables.get(key + ("independent",)) if tree.independent_rows else None) \
+                    or self.tree_callables.get(key)
             if runner is not None:
                 return runner.replay(input_ids, storage_ids, position_ids, tree=tree, borrow=borrow)
             return self.inference(input_ids, storage_ids, position_ids, attn_mask, tree=tree)

@@ -48,6 +48,11 @@ class TreeContext:
     # (its nodes are leaves: no child is ever sampled from their rows, Tree/SpecTree.py:103).  The tall-skinny forward
     # then stops after the last layer's RoPE + KV write (Engine/ts_linear.py::forward_ts) and returns None.
     need_logits: bool = True
+    # True: no query of this forward may see another query's key (only its own) -- the draft forward over ONE tree level
+    # (the new nodes of a level are siblings / cousins, none is another's ancestor: Tree/SpecTree.py:87-134).  Small drafts
+    # then run the attention half of every layer as one launch (csrc/draft_block.hip, Engine/ts_linear.py::attn_block_ok);
+    # a one-row forward qualifies without the flag.
+    independent_rows: bool = False
 
 
 @dataclass

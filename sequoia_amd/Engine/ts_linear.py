@@ -414,6 +414,32 @@ def forward_small_fused(model, ts: "TsLinearSet", ids, q_len, pos, storage_ids, 
     return logits.unsqueeze(0)
 
 
+# Small drafts (heads of 64, hidden 512 / 768 / 1024: the 68m / 160m models), forwards whose rows never see each other (one
+# tree level; any one-row forward): qkv projection + RoPE + KV write + tree attention + o_proj of a layer run as ONE launch
+# per layer (csrc/draft_block.hip) instead of four -- each of the four sits on the ~5 us floor of a dependent graph node.
+# o_proj comes out as per-head fp32 partials that the residual add + RMSNorm sums (splits = heads).
+DRAFT_BLOCK = os.environ.get("SEQUOIA_DRAFT_BLOCK", "1") == "1"
+BLOCK_MAX_ROWS = int(os.environ.get("SEQUOIA_DRAFT_BLOCK_ROWS", str(MAX_ROWS)))
+
+
+def block_capable(model, q_len: int) -> bool:
+    """The model / row count side of attn_block_ok (what a graph runner needs to know before it captures a variant)."""
+    d, ts = model.dims, getattr(model, "ts", None)
+    return (DRAFT_BLOCK and ts is not None and q_len <= min(BLOCK_MAX_ROWS, MAX_ROWS) and d.head_dim == 64
+            and d.local_heads == d.local_kv_heads and d.local_heads <= 16 and d.hidden_size in (512, 768, 1024)
+            and model.reduce_fn is None and d.tp_world == 1 and ts.shapes["o"][1] == d.local_heads * 64
+            and ts.shapes["qkv"][0] == 3 * d.local_heads * 64 and ts._slab.numel() >= d.local_heads * q_len * d.hidden_size)
+
+
+def attn_block_ok(model, ts: "TsLinearSet", q_len: int, tree) -> bool:
+    if not (tree is not None and (q_len == 1 or tree.independent_rows) and tree.contiguous_slots
+            and block_capable(model, q_len)):
+        return False
+    # the weight images are made outside any capture (the eager warm-up of a graph comes first)
+    have = ("qkv", 0) in ts._frag and ("o", 0) in ts._frag
+    return have or not torch.cuda.is_current_stream_capturing()
+
+
 def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree, kv_cache):
     """Decoder forward of <= MAX_ROWS tree tokens on the tall-skinny projections.  ids: int64 [q] token ids.
     Returns logits [1, q, V].  Tensor-parallel shards (model.reduce_fn set): the partial output of the row-parallel
@@ -457,6 +483,10 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
         return ("rows", reduce_fn(rows))
 
     reduce_norm_fn = getattr(model, "reduce_norm_fn", None) if reduce_fn is not None else None
+    use_block = attn_block_ok(model, ts, q_len, tree)
+    if use_block and not torch.cuda.is_current_stream_capturing():
+        for li in range(len(W.layers)):
+            ts.frag("qkv", li); ts.frag("o", li)
 
     def reduce_norm(partial, weight, want_frag):
         """Tensor-parallel continuation of a row-parallel projection: x += all-reduce(partial); RMSNorm into the next operand.
@@ -500,26 +530,35 @@ def forward_ts(model, ts: TsLinearSet, ids, q_len, pos, storage_ids, dense, tree
     pending = None
     for li, lw in enumerate(W.layers):
         if li == 0:                                              # embedding lookup + first norm, one launch
-            want = plan["qkv"] is not None
+            want = use_block or plan["qkv"] is not None
             h = torch.empty(fs(q_len, hidden) if want else (q_len, hidden), dtype=dt, device=dev)
             if stage is not None:      # device-driven step: ids / positions / slots / context staged by the same launch
                 ops.embed_stage_rmsnorm(stage, W.embed, lw.ln1, x, h, eps, out_frag=want)
             else:
                 ops.embed_rmsnorm(ids, W.embed, lw.ln1, x, h, eps, out_frag=want)
         else:
-            h = reduce_norm(pending, lw.ln1, plan["qkv"] is not None)
-        qkv = project("qkv", li, h)
+            h = reduce_norm(pending, lw.ln1, use_block or plan["qkv"] is not None)
         stop = kv_only and li == len(W.layers) - 1
-        if qkv[0] == "slab":
-            attn = attention_core(None, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
-                                  out_frag=plan["o"] is not None, qkv_slab=(slab, qkv[1], q_len), kv_only=stop)
+        if use_block:            # qkv + RoPE + KV write + attention + o_proj partials: one launch
+            nh = dims.local_heads
+            ops.draft_attn_block(h, ts.frag("qkv", li), None if stop else ts.frag("o", li), slab, kv_cache.k_cache[li, 0],
+                                 kv_cache.v_cache[li, 0], model.cos, model.sin, pos, storage_ids, q_len, nh, dims.head_dim,
+                                 hidden, dims.head_dim ** -0.5, tree.q_slot0, tree.gt, tree.n_tree, tree.bitmask, tree.ctx,
+                                 kv_only=stop)
+            o_part = ("slab", nh)
         else:
-            attn = attention_core(qkv[1], li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
-                                  out_frag=plan["o"] is not None, kv_only=stop)
+            qkv = project("qkv", li, h)
+            if qkv[0] == "slab":
+                attn = attention_core(None, li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
+                                      out_frag=plan["o"] is not None, qkv_slab=(slab, qkv[1], q_len), kv_only=stop)
+            else:
+                attn = attention_core(qkv[1], li, dims, kv_cache, model.cos, model.sin, pos, storage_ids, dense, tree,
+                                      out_frag=plan["o"] is not None, kv_only=stop)
+            o_part = None if stop else project("o", li, attn)
         if stop:                 # nothing downstream of the last layer's K / V rows is needed
             kv_cache.note_written(q_len)
             return None
-        h = reduce_norm(project("o", li, attn), lw.ln2, plan["gate_up"] is not None)
+        h = reduce_norm(o_part, lw.ln2, plan["gate_up"] is not None)
         down_ts = plan["down"] is not None
         act = torch.empty(fs(q_len, inter) if down_ts else (q_len, inter), dtype=dt, device=dev)
         if plan["gate_up"] is not None:

@@ -169,10 +169,11 @@ class NativeTree(Tree):
         """The acceptance uniforms r[slot] (Tree/SpecTree.py:60: fp16, drawn on the CPU generator)."""
         return torch.rand(m, dtype=self.dtype)
 
-    def _ctx(self, q_slot0: int, kv_len: int) -> TreeContext:
+    def _ctx(self, q_slot0: int, kv_len: int, independent_rows: bool = False) -> TreeContext:
         # storage_ids = arange(M) (Tree/SpecTree.py:63): the queries' KV slots are q_slot0 + arange(q_len)
         return TreeContext(q_slot0=q_slot0, gt=self.ground_truth_len, n_tree=self.tree_size,
-                           bitmask=self.gdev["bitmask"], kv_len=kv_len, contiguous_slots=True)
+                           bitmask=self.gdev["bitmask"], kv_len=kv_len, contiguous_slots=True,
+                           independent_rows=independent_rows)
 
     def _sample_level(self, i: int, lv: dict):
         raise NotImplementedError
@@ -202,7 +203,9 @@ class NativeTree(Tree):
             input_ids=self.tokens[self.draft_kv_len:end_pos].unsqueeze(0),
             position_ids=self.position_ids[start_pos:end_pos].unsqueeze(0),
             attn_mask=None, storage_ids=self.storage_ids[self.draft_kv_len:end_pos],
-            tree=self._ctx(self.draft_kv_len, end_pos), borrow=True)
+            # exactly the level's new nodes (the usual case: the draft cache is current up to start_pos): rows that never
+            # see each other
+            tree=self._ctx(self.draft_kv_len, end_pos, independent_rows=self.draft_kv_len == start_pos), borrow=True)
         self.draft_kv_len = end_pos
         first = start_pos - self.ground_truth_len + 1
         self.draft_logits[first:first + total_branch] = logits[0][-total_branch:]

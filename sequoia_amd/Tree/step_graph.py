@@ -44,14 +44,14 @@ OVERLAP_LAST_LEVEL = os.environ.get("SEQUOIA_OVERLAP_LAST_LEVEL", "0")
 class _Fwd:
     """Static inputs of one forward of fixed q_len (the analogue of a _GraphRunner's buffers)."""
 
-    def __init__(self, q_len, n_tree, bitmask, device):
+    def __init__(self, q_len, n_tree, bitmask, device, independent_rows=False):
         self.q_len = q_len
         self.ids = torch.zeros((1, q_len), dtype=torch.long, device=device)
         self.pos = torch.zeros((1, q_len), dtype=torch.long, device=device)
         self.sto = torch.zeros(q_len, dtype=torch.long, device=device)
         self.ctx = torch.tensor([0, 1, q_len], dtype=torch.int32, device=device)
         self.tree = TreeContext(q_slot0=0, gt=1, n_tree=n_tree, bitmask=bitmask, kv_len=q_len, ctx=self.ctx,
-                                contiguous_slots=True)
+                                contiguous_slots=True, independent_rows=independent_rows)
 
 
 class StepState:
@@ -104,7 +104,8 @@ class StepState:
         self.ring_np = self.ring.numpy().reshape(SQ_RESULT_RING, SQ_RESULT_INTS) if self.ring.device.type == "cpu" else None
         self.verify_ws = self.ops.verify_workspace(n, dev)
         bm = self.gdev["bitmask"]
-        self.fwd_levels = [_Fwd(lv["total"], n, bm, dev) for lv in self.gdev["levels"]]
+        # the new nodes of one tree level never see each other (none is another's ancestor): TreeContext.independent_rows
+        self.fwd_levels = [_Fwd(lv["total"], n, bm, dev, independent_rows=True) for lv in self.gdev["levels"]]
         self.fwd_target = _Fwd(n, n, bm, dev)
         self.fwd_one = _Fwd(1, n, bm, dev)
         self.graph = None

@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libsequoia_hip.so")
-SOURCES = ["kv_ops.hip", "sampler.hip", "verify.hip", "tree_attention.hip", "fused_ops.hip", "ts_linear.hip", "allreduce.hip", "draft_fused.hip"]
+SOURCES = ["kv_ops.hip", "sampler.hip", "verify.hip", "tree_attention.hip", "fused_ops.hip", "ts_linear.hip", "allreduce.hip", "draft_fused.hip", "draft_block.hip"]
 # measurement aids (tools/prefetch_probe.py) stay out of the product library: SEQUOIA_BUILD_PROBES=1 adds them
 PROBES = os.environ.get("SEQUOIA_BUILD_PROBES", "0") == "1"
 if PROBES:

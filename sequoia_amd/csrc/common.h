@@ -218,6 +218,12 @@ __device__ __forceinline__ void slab_sum8(const float* const (&sp)[NP], int spli
     case 2: slab_sum8_n<2, NP>(sp, stride, lo, hi); break;
     case 3: slab_sum8_n<3, NP>(sp, stride, lo, hi); break;
     case 4: slab_sum8_n<4, NP>(sp, stride, lo, hi); break;
+    case 6: slab_sum8_n<6, NP>(sp, stride, lo, hi); break;
+    case 8: slab_sum8_n<8, NP>(sp, stride, lo, hi); break;
+    case 12:                                               // per-head partials of the fused draft attention block (12 / 16 heads,
+        if constexpr (NP == 1) { slab_sum8_n<12, NP>(sp, stride, lo, hi); break; }      // csrc/draft_block.hip): one place per thread
+    case 16:
+        if constexpr (NP == 1) { if (splits == 16) { slab_sum8_n<16, NP>(sp, stride, lo, hi); break; } }
     default:
         slab_sum8_n<4, NP>(sp, stride, lo, hi);
         for (int s = 4; s < splits; ++s)

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libsequoia_hip.so")
+# (SEQUOIA_LIB: an experiment build of the same ABI, e.g. tools/block_dbg_build.sh -- never a different implementation)
+LIB_PATH = os.environ.get("SEQUOIA_LIB") or os.path.join(_PKG, "lib", "libsequoia_hip.so")
 
 SQ_OK, SQ_EINVAL, SQ_EUNSUPPORTED, SQ_ELAUNCH = 0, -1, -2, -3
 SQ_MAX_TREE = 512
@@ -73,6 +74,8 @@ PROTOTYPES = {
     "sq_silu_mul_frag_f16": (_i, [_vp, _vp, _i, _i, _vp]),
     "sq_silu_mul_slabs_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "sq_norm_linear_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sq_draft_attn_block_f16": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i,
+                                     _vp, _i, _vp, _i, _vp]),
     "sq_ar_workspace_bytes": (C.c_size_t, [_i, C.c_size_t, C.c_size_t]),
     "sq_ar_alloc": (_i, [C.POINTER(_vp), C.c_size_t]),
     "sq_ar_free": (_i, [_vp]),

@@ -466,6 +466,35 @@ class HipOps:
               "sq_norm_linear_f16")
         return out
 
+    def draft_attn_block(self, a_frag, wqkv_frag, wo_frag, slab, k_layer, v_layer, cos, sin, position_ids, storage_ids,
+                         q_len, n_heads, d, hidden, scale, q_slot0, gt, n_tree, bitmask=None, ctx=None, kv_only=False):
+        """The attention half of a small draft's decoder layer in one launch (csrc/draft_block.hip): q|k|v projection,
+        RoPE, KV write, tree attention over the cached keys + the row's own key, per-head o_proj partials into
+        slab[n_heads][q_len][hidden] (summed by add_rmsnorm_slabs with splits = n_heads).  Rows must not see each other."""
+        _need(a_frag, torch.float16, "a_frag"); _need(wqkv_frag, torch.float16, "wqkv_frag")
+        _need(k_layer, torch.float16, "k_layer"); _need(v_layer, torch.float16, "v_layer")
+        _need(cos, torch.float16, "cos"); _need(sin, torch.float16, "sin")
+        _need(position_ids, torch.int64, "position_ids"); _need(storage_ids, torch.int64, "storage_ids")
+        assert position_ids.numel() >= q_len and storage_ids.numel() >= q_len
+        assert a_frag.numel() >= ((q_len + 15) // 16) * 16 * hidden and wqkv_frag.numel() == 3 * n_heads * d * hidden
+        m = k_layer.shape[-2]
+        words = 0
+        if bitmask is not None:
+            _need(bitmask, torch.int64, "bitmask")
+            words = bitmask.shape[1]
+        slab_bytes = 0
+        if not kv_only:
+            _need(wo_frag, torch.float16, "wo_frag"); _need(slab, torch.float32, "slab")
+            assert wo_frag.numel() == hidden * n_heads * d
+            slab_bytes = slab.numel() * 4
+        check(self.lib.sq_draft_attn_block_f16(a_frag.data_ptr(), wqkv_frag.data_ptr(), _ptr(wo_frag), _ptr(slab), slab_bytes,
+                                               k_layer.data_ptr(), v_layer.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                               position_ids.data_ptr(), storage_ids.data_ptr(), int(q_len), int(n_heads),
+                                               int(d), int(hidden), int(m), float(scale), int(q_slot0), int(gt), int(n_tree),
+                                               _ptr(bitmask), int(words), _ptr(ctx), 1 if kv_only else 0, self._stream()),
+              "sq_draft_attn_block_f16")
+        return slab
+
     def add_rmsnorm_slabs(self, slab, splits, residual, sum_out, weight, out, eps, out_frag=False):
         """x = h(sum of the split-K partials); sum_out = x + residual; out = RMSNorm(sum_out) * weight
         (out None: add only)."""

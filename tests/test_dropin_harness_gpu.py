@@ -131,3 +131,99 @@ def test_utils_factories_match_oracle():
     p = torch.softmax(logits[0].float(), -1).half(); q = torch.softmax(logits[1].float(), -1).half()
     res = U.cuda_graph_for_residual()(p, q)
     assert abs(float(res.float().sum()) - 1.0) < 2e-2
+
+
+@pytest.mark.parametrize("seed", [24, 25, 28])
+def test_reference_harness_record_replays_on_gpu(seed):
+    """tests/golden/harness_simulation_fast_<seed>.npz are runs of the reference's own `simulation_fast` source on the
+    reference's classes (oracle/ref_harness.py compiles tests/testbed.py:35-40,45-95,250-285,297-298 from the file's AST;
+    tests/test_reference_harness_cpu.py executes the same lines on the drop-in with the numpy oracle, token-identical).  The
+    reference's file cannot travel to the GPU box, so here its body is RE-TYPED on the record's inputs -- seeded weights,
+    prompts, noise and bonus uniforms pinned as on the CPU -- and the HIP library must hand the harness loop the reference's
+    tokens in every verify call."""
+    import numpy as np
+    from oracle import ref_harness as RH
+    import sequoia_amd.dropin as dropin
+    z, meta = RH.load_record(os.path.join(REPO, "tests", "golden", f"harness_simulation_fast_{seed}.npz"))
+    dropin.install(force=True)
+    try:
+        from Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
+        from Tree.SpecTree import SpecTree
+        from utils import cuda_graph_for_residual, cuda_graph_for_sampling_without_replacement
+        from sequoia_amd.growmap import GrowMap
+        M, T, P = meta["M"], meta["T"], meta["top_p"]
+        os.environ["SEQUOIA_HARNESS_GAIN"], os.environ["SEQUOIA_HARNESS_SHARE"] = str(meta["gain"]), str(meta["share"])
+        sd_d, sd_t, checks = RH.seeded_pair(meta["seed"])
+        assert checks == meta["weight_checksums"]
+        hidden, inter, layers, heads, kv = meta["dims"]
+        cfg = dict(vocab_size=meta["vocab"], hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                   num_attention_heads=heads, num_key_value_heads=kv, max_position_embeddings=2048)
+        # ---- set-up block (tests/testbed.py:250-285) --------------------------------------------------------------
+        draft_model = GraphInferenceEngine(max_length=M, model_name_or_path=dict(state_dict=sd_d, config=cfg), dtype=torch.float16,
+                                           device="cuda:0")
+        target_model = GraphInferenceEngineTG(max_length=M, model_name_or_path=dict(state_dict=sd_t, config=cfg),
+                                              dtype=torch.float16, device="cuda:0")
+        residual_graph = cuda_graph_for_residual()
+        grow_map = GrowMap.from_successors(meta["successors"]).to_reference_dict()
+        tree_size = grow_map["size"]
+        idx_lists, branch_lists = grow_map["roots"], grow_map["branches"]
+        draft_step = len(grow_map["roots"])
+        graph_capture_list = [sum(x) for x in branch_lists]
+        graph_capture_list.append(1)
+        draft_model.initialize_cuda_graph(graph_capture_list)
+        sampling_callables, sample_gather_indices = {}, {}
+        for i in range(draft_step - 1):
+            sampling_callables[i] = cuda_graph_for_sampling_without_replacement(
+                max_length=M, idx_len=len(idx_lists[i]), num_samples=max(branch_lists[i]), temperature=T, tree_size=tree_size)
+        for i in range(draft_step - 1):
+            ith = []
+            for j, branch in enumerate(branch_lists[i]):
+                ith.append(torch.arange(branch, device="cuda:0", dtype=torch.long) + j * max(branch_lists[i]))
+            sample_gather_indices[i] = torch.cat(ith)
+        # ---- simulation_fast (tests/testbed.py:45-95) ---------------------------------------------------------------
+        dtype = torch.float16
+        attn_mask = torch.full((M, M), torch.finfo(dtype).min, dtype=dtype, device="cuda:0")
+        sequence = torch.tensor(list(range(M)), device="cuda:0").long().unsqueeze(-1)
+        new_tokens_buffer = torch.zeros(M).long().to("cuda:0")
+        parents_buffer = torch.zeros(M).long().to("cuda:0")
+        position_ids = torch.zeros(M).long().to("cuda:0")
+        num_decoding_steps = num_large_model_steps = 0
+        u24 = z["bonus_u24"]
+        j = 0
+        with torch.no_grad():
+            for step in range(meta["n_prompts"]):
+                input_ids = torch.from_numpy(z[f"prompt{step}/input_ids"])[..., :128]
+                labels = torch.from_numpy(z[f"prompt{step}/labels"])[..., :128]
+                terminate = False
+                if labels[0][-1] == -100:
+                    terminate = True
+                attn_mask.fill_(torch.finfo(dtype).min)
+                torch.manual_seed(RH.noise_seed(meta["seed"], step))          # the pins of oracle/ref_harness.py's SpySpecTree
+                spectree = SpecTree(prefix=input_ids.squeeze(0), device="cuda:0", temperature=T, top_p=P, draft_kv_len=0,
+                                    target_kv_len=0, draft_model_engine=draft_model, target_model_engine=target_model,
+                                    max_length=M, max_target_seq=M, grow_map=grow_map, attn_mask=attn_mask, sequence=sequence,
+                                    new_tokens_buffer=new_tokens_buffer, parents_buffer=parents_buffer,
+                                    position_ids=position_ids, residual_graph=residual_graph,
+                                    sampling_callables=sampling_callables, sample_gather_indices=sample_gather_indices,
+                                    bonus_uniforms=[int(x) for x in u24[step * RH.STEPS_PER_PROMPT:(step + 1) * RH.STEPS_PER_PROMPT]],
+                                    commit_order="reference")
+                torch.cuda.synchronize()
+                while input_ids.shape[1] < 256 and terminate is False:
+                    spectree.construct_grow_map()
+                    valid_tokens, draft_kv_len, target_kv_len, terminate = spectree.verify()
+                    assert j < meta["n_verify"] and int(z[f"verify{j}/prompt"]) == step
+                    assert np.array_equal(valid_tokens.cpu().numpy(), z[f"verify{j}/tokens"]), \
+                        f"verify call {j} (prompt {step}): tokens differ from the reference's harness run"
+                    j += 1
+                    num_decoding_steps += valid_tokens.shape[0] - input_ids.shape[1]
+                    num_large_model_steps += 1
+                    input_ids = valid_tokens.unsqueeze(0)
+                    if (input_ids[0][-1] == 2) or (input_ids[0][-1] == 0):
+                        terminate = True
+                torch.cuda.synchronize()
+                draft_model.clear_kv()
+                target_model.clear_kv()
+        assert j == meta["n_verify"]
+        assert num_decoding_steps / num_large_model_steps == meta["value"]
+    finally:
+        dropin.uninstall()
