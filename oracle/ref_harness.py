@@ -119,12 +119,13 @@ def make_inputs(seed):
     return batches, u24
 
 
-def seeded_pair(seed):
+def seeded_pair(seed, gain=None, share=None, branch=None):
     """(draft, target) state dicts + their checksums: the same bits on both sides."""
     from oracle import seeded_weights as SW
-    sd_t = SW.seeded_state_dict(TINY, VOCAB, 1000 + seed, GAIN, branch_scale=BRANCH)
-    sd_d = SW.seeded_state_dict(TINY, VOCAB, 2000 + seed, GAIN, branch_scale=BRANCH)
-    SW.correlate(sd_d, sd_t, SHARE, 3000 + seed)
+    gain, share, branch = GAIN if gain is None else gain, SHARE if share is None else share, BRANCH if branch is None else branch
+    sd_t = SW.seeded_state_dict(TINY, VOCAB, 1000 + seed, gain, branch_scale=branch)
+    sd_d = SW.seeded_state_dict(TINY, VOCAB, 2000 + seed, gain, branch_scale=branch)
+    SW.correlate(sd_d, sd_t, share, 3000 + seed)
     return sd_d, sd_t, [str(SW.checksum(sd_d)), str(SW.checksum(sd_t))]
 
 
@@ -259,7 +260,7 @@ def run_dropin(z, meta, device="cpu", growmap=None, code=None):
         u24 = z["bonus_u24"]
         log, state = [], dict(prompt=-1)
 
-        sd_d, sd_t, checks = seeded_pair(seed)
+        sd_d, sd_t, checks = seeded_pair(seed, meta.get("gain"), meta.get("share"), meta.get("branch"))
         assert checks == meta["weight_checksums"], "seeded weights differ from the reference run's (torch CPU generator drift)"
         sds = dict(draft=sd_d, target=sd_t)
         hidden, inter, layers, heads, kv = meta["dims"]
