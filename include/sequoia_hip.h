@@ -498,6 +498,19 @@ int sq_draft_attn_block_f16(const void* a_frag, const void* wqkv_frag, const voi
                             int hidden, int m, float scale, int q_slot0, int gt, int n_tree, const uint64_t* d_bitmask,
                             int words, const int32_t* d_ctx, int kv_only, void* stream);
 
+/* RoPE + KV write + tree attention of one layer in ONE launch, for forwards whose rows never attend to each other (one tree
+ * level, or one row) of ANY model with heads of 64 or 128: replaces sq_rope_kv_write_f16 or sq_rope_kv_write_slabs_f16 followed by
+ * sq_tree_attention_f16 (LlamaAttention_FI.forward, Engine/Llama_modules.py:104-136, without the kernel boundary between
+ * them).  qkv: the projection's fp16 rows [q_len][qkv_stride] -- or qkv_slab: its fp32 split-K partials
+ * [splits][q_len][qkv_stride] (sq_linear_ts_f16), summed in split order and rounded to fp16 first.  out: fp16 [q_len][H d],
+ * or (out_frag != 0) its fragment-major image for sq_linear_ts_f16.  Same caller guarantees and mask rule as
+ * sq_draft_attn_block_f16; GQA: the first query head of a KV group writes the group's K / V rows.                        */
+int sq_level_attention_f16(const void* qkv, const float* qkv_slab, int splits, int qkv_stride, void* out, int out_frag,
+                           void* k_layer, void* v_layer, const void* cos_tab, const void* sin_tab,
+                           const int64_t* d_position_ids, const int64_t* d_storage_ids, int q_len, int n_heads, int h_kv, int d,
+                           int m, float scale, int q_slot0, int gt, int n_tree, const uint64_t* d_bitmask, int words,
+                           const int32_t* d_ctx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

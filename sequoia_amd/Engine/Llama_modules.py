@@ -10,12 +10,17 @@ tensor-parallel shards; tree forwards of <= 128 rows run Engine/ts_linear.py ins
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
 import torch.nn.functional as F
 
 from ..ops import get_ops
+
+# "1" (default): a forward whose rows never see each other -- the draft forward over one tree level, any one-row forward --
+# runs RoPE + KV write + tree attention of a layer as one launch (csrc/draft_block.hip::level_attention_kernel) instead of two
+LEVEL_ATTENTION = os.environ.get("SEQUOIA_LEVEL_ATTENTION", "1") == "1"
 
 
 def rope_tables(head_dim: int, max_pos: int, base: float, device, dtype=torch.float16):
@@ -79,6 +84,13 @@ def attention_core(qkv, layer_idx: int, dims, kv_cache, cos, sin, position_ids, 
     attn = torch.empty(ops.frag_shape(q_len, n_heads * d) if out_frag else (q_len, n_heads * d), dtype=dt, device=dev)
     scale = 1.0 / math.sqrt(d)
     frag_kw = dict(out_frag=True) if out_frag else {}
+    if (LEVEL_ATTENTION and not kv_only and tree is not None and (q_len == 1 or tree.independent_rows)
+            and tree.contiguous_slots and d in (64, 128) and hasattr(ops, "level_attention")):
+        # rows that never see each other (one tree level / one row): RoPE + KV write + attention are ONE launch
+        ops.level_attention(qkv, attn, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d, scale,
+                            tree.q_slot0, tree.gt, tree.n_tree, bitmask=tree.bitmask, ctx=tree.ctx, out_frag=out_frag,
+                            qkv_slab=None if qkv_slab is None else (qkv_slab[0], qkv_slab[1], q_len, (n_heads + 2 * h_kv) * d))
+        return attn
     q_rot = torch.empty((n_heads, q_len, d), dtype=dt, device=dev)
     if qkv_slab is not None:
         ops.rope_kv_write_slabs(qkv_slab[0], qkv_slab[1], (n_heads + 2 * h_kv) * d, q_rot, k_layer, v_layer, cos, sin,

@@ -39,7 +39,7 @@ def _stale(target: str, deps: list[str]) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "sequoia_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_map.h"), os.path.join(os.path.dirname(PKG), "include", "sequoia_hip.h")]
     objs = []
     cc = hipcc()
     for s in srcs:

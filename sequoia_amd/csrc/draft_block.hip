@@ -26,6 +26,7 @@
 // Reference lines replaced: LlamaAttention_FI.forward (Engine/Llama_modules.py:87-140): q/k/v_proj, rotary embedding,
 // kv_cache.update_kv_cache, the masked softmax attention, o_proj.
 #include "common.h"
+#include "attn_map.h"
 
 #define DB_WAVES 8
 #define DB_THREADS (DB_WAVES * 64)
@@ -35,7 +36,7 @@
 #define DB_QS (DB_D + 8)             // halves per row of the q / k / v / o LDS tiles (16-byte aligned rows, de-phased banks)
 #define DB_MAX_WORDS (SQ_MAX_TREE / 64)
 // Compile-time experiment switch (tools/block_dbg_build.sh): the full kernel returns after 1 = phase 2, 2 = the attention
-// prologue, 3 = the key loop, 4 = the merge.  Not a run-time branch: the timeline of the phases is read from the differences.
+// prologue [removed], 3 = the key loop [removed], 4 = the attention.  Not a run-time branch: the timeline of the phases is read from the differences.
 #ifndef DB_STOP
 #define DB_STOP 0
 #endif
@@ -91,16 +92,228 @@ template <int NT>
 struct DbLds {
     static constexpr int LDW = NT * 16 + 4;                                   // floats per partial row
     static constexpr int PART = DB_WAVES * DB_BM * LDW * 4;
-    static constexpr int KV_TILE = 2 * DB_BK * DB_QS;                          // halves per wave: V tile then K tile
-    static constexpr int ATT_V = DB_WAVES * KV_TILE * 2;
-    static constexpr int OSTR = DB_D + 4;
-    static constexpr int ATT_O = DB_WAVES * DB_BM * OSTR * 4;
-    static constexpr int MAIN = PART > ATT_V ? (PART > ATT_O ? PART : ATT_O) : (ATT_V > ATT_O ? ATT_V : ATT_O);
+    static constexpr int ATT = 2 * DB_BK * DB_QS * 2 * DB_WAVES > DB_WAVES * DB_BM * (DB_D + 4) * 4
+                                   ? 2 * DB_BK * DB_QS * 2 * DB_WAVES : DB_WAVES * DB_BM * (DB_D + 4) * 4;     // == DbAtt<DB_D>::MAIN
+    static constexpr int MAIN = PART > ATT ? PART : ATT;
     static constexpr int QKVO = MAIN;                                          // q_s, k_s, v_s, o_s: [16][DB_QS] halves each
     static constexpr int ML = QKVO + 4 * DB_BM * DB_QS * 2;                    // [wave][16][2] floats
     static constexpr int BM = ML + DB_WAVES * DB_BM * 8;                       // [16][DB_MAX_WORDS] u64
     static constexpr int TOTAL = BM + DB_BM * DB_MAX_WORDS * 8;
 };
+
+
+// ---- the attention of one (head, 16-query tile) over the CACHED keys [0, n_keys) plus each query's own key -------------------
+// Shared by the fused block below (D = 64) and by level_attention_kernel (D = 64 / 128).  Inputs in LDS: q_s / k_s / v_s =
+// the tile's rotated queries, rotated keys and values ([16][D + 8] fp16); lds_bm = the queries' ancestor-bitmask rows
+// ([16][DB_MAX_WORDS]); kr_cur / vr_cur = this wave's first chunk of cached K / V rows, already requested by the caller.
+// Output: o_s ([16][D + 8] fp16, may alias q_s) = softmax(QK^T / sqrt(D)) V rounded to fp16, visible to every wave on return.
+// 32-key chunks are dealt over the 8 waves (wave-private LDS tiles, next chunk in flight in registers), both contractions run
+// on v_mfma_f32_16x16x32_f16 (S^T = K Q^T, O^T += V^T P^T with V^T through ds_read_b64_tr_b16), the online-softmax state is
+// per wave and merged through LDS -- the structure of csrc/tree_attention.hip; the query's OWN key (the only key of this forward
+// it may see) is one more online-softmax step on the vector ALU of the wave with the fewest chunks.
+template <int D>
+struct DbAtt {
+    static constexpr int QS = D + 8;                                           // halves per LDS row
+    static constexpr int CPR = D / 8;                                          // 16-byte chunks per K / V row
+    static constexpr int VITER = DB_BK * CPR / 64;                             // 16-byte K (and V) loads per lane and chunk
+    static constexpr int NTO = D / 16;                                         // output column tiles
+    static constexpr int DSTEPS = D / 32;                                      // MFMA k-steps of S^T
+    static constexpr int KV_TILE = 2 * DB_BK * QS;                             // halves per wave: V tile then K tile
+    static constexpr int ATT_V = DB_WAVES * KV_TILE * 2;
+    static constexpr int OSTR = D + 4;
+    static constexpr int ATT_O = DB_WAVES * DB_BM * OSTR * 4;
+    static constexpr int MAIN = ATT_V > ATT_O ? ATT_V : ATT_O;                 // bytes of the K / V tiles, reused by the merge
+};
+
+template <int D>
+__device__ __forceinline__ void db_issue_kv(int chunk, int n_keys, int lane, const half_t* kbase, const half_t* vbase,
+                                            u32x4 (&kr)[DbAtt<D>::VITER], u32x4 (&vr)[DbAtt<D>::VITER]) {
+    constexpr int CPR = DbAtt<D>::CPR;
+    const int key0 = chunk * DB_BK;
+#pragma unroll
+    for (int it = 0; it < DbAtt<D>::VITER; ++it) {
+        const int idx = it * 64 + lane;
+        const int r = idx / CPR, c = idx % CPR;
+        int row = key0 + r; if (row >= n_keys) row = n_keys - 1;
+        kr[it] = *(const u32x4*)(kbase + (size_t)row * D + c * 8);
+        vr[it] = *(const u32x4*)(vbase + (size_t)row * D + c * 8);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void db_attend(const half_t* q_s, const half_t* k_s, const half_t* v_s, half_t* o_s,
+                                          unsigned char* lds_main, float* lds_ml, const uint64_t* lds_bm,
+                                          u32x4 (&kr_cur)[DbAtt<D>::VITER], u32x4 (&vr_cur)[DbAtt<D>::VITER],
+                                          const half_t* kbase, const half_t* vbase, int n_keys, int q0, int q_len, int q_slot0,
+                                          int gt, int n_tree, int words, float scale_log2e, int tid, int wave) {
+    using A = DbAtt<D>;
+    constexpr int QS = A::QS, CPR = A::CPR, VITER = A::VITER, NTO = A::NTO, DSTEPS = A::DSTEPS;
+    const int lane = tid & 63, qc = lane & 15, g = lane >> 4;
+    const int n_chunks = (n_keys + DB_BK - 1) / DB_BK;
+    half_t* lds_v = (half_t*)lds_main;
+    float* lds_o = (float*)lds_main;
+    const int qi_c = min(q0 + qc, q_len - 1);
+    const int slot = q_slot0 + qi_c;
+    const int tnode = slot - (gt - 1);
+    const bool causal_row = slot < gt;
+    const bool tree_ok = tnode < n_tree;
+
+    // Q fragments (B operand): lane (n = qc, g) holds Q[qc][32 s + 8 g .. +8]; this lane's share of q . k of its own row
+    half8 qf[DSTEPS];
+#pragma unroll
+    for (int s = 0; s < DSTEPS; ++s) qf[s] = *(const half8*)(q_s + qc * QS + s * 32 + g * 8);
+    float s_diag = 0.f;
+#pragma unroll
+    for (int c = 0; c < D / 32; ++c) {                            // the lane's D / 4 elements of the row, 8 at a time
+        const half8 kk = *(const half8*)(k_s + qc * QS + g * (D / 4) + c * 8), qq = *(const half8*)(q_s + qc * QS + g * (D / 4) + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_diag += (float)qq[e] * (float)kk[e];
+    }
+    s_diag = db_group4_sum(s_diag);
+    __syncthreads();                                              // every wave holds its fragments: the K / V tile area is free
+
+    float m_run = -INFINITY, l_run = 0.f;
+    floatx4 o_acc[NTO];
+#pragma unroll
+    for (int i = 0; i < NTO; ++i) o_acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    half_t* my_v = lds_v + wave * A::KV_TILE;
+    half_t* my_k = my_v + DB_BK * QS;
+    u32x4 kr_nxt[VITER], vr_nxt[VITER];
+    for (int ch = wave; ch < n_chunks; ch += DB_WAVES) {
+        const int key0 = ch * DB_BK;
+        const bool has_next = ch + DB_WAVES < n_chunks;
+        if (has_next) db_issue_kv<D>(ch + DB_WAVES, n_keys, lane, kbase, vbase, kr_nxt, vr_nxt);
+#pragma unroll
+        for (int it = 0; it < VITER; ++it) {
+            const int idx = it * 64 + lane;
+            *(u32x4*)(my_k + (idx / CPR) * QS + (idx % CPR) * 8) = kr_cur[it];
+            *(u32x4*)(my_v + (idx / CPR) * QS + (idx % CPR) * 8) = vr_cur[it];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // S^T = K Q^T: lane (q = qc, g) receives keys key0 + 16 t + 4 g + r
+        floatx4 s_acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            floatx4 a = {0.f, 0.f, 0.f, 0.f};
+            half8 kf[DSTEPS];
+#pragma unroll
+            for (int s = 0; s < DSTEPS; ++s) kf[s] = *(const half8*)(my_k + (t * 16 + qc) * QS + s * 32 + g * 8);
+#pragma unroll
+            for (int s = 0; s < DSTEPS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[s], qf[s], a, 0, 0, 0);
+            s_acc[t] = a;
+        }
+        float sv[8];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + t * 16 + g * 4 + r;
+                float x = s_acc[t][r] * scale_log2e;
+                const int j = key - (gt - 1);
+                const uint64_t wv = lds_bm[qc * DB_MAX_WORDS + (((unsigned)j >> 6) < (unsigned)words ? (j >> 6) : 0)];
+                const bool bit = (wv >> (j & 63)) & 1ull;
+                const bool vis_tree = (key < gt) | (tree_ok & ((unsigned)j < (unsigned)n_tree) & bit);
+                const bool vis = (key < n_keys) & (causal_row | vis_tree);     // (a committed-text row sees every key in front of it)
+                x = vis ? x : -INFINITY;
+                sv[t * 4 + r] = x;
+                cmax = fmaxf(cmax, x);
+            }
+        cmax = db_group4_max(cmax);
+        const float m_new = fmaxf(m_run, cmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        half8 pf;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = __builtin_amdgcn_exp2f(sv[j] - m_use);
+            psum += p;
+            pf[j] = (half_t)p;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            const half_t* a0 = my_v + (0 * 16 + g * 4 + (qc >> 2)) * QS + nt * 16 + (qc & 3) * 4;
+            const half_t* a1 = my_v + (1 * 16 + g * 4 + (qc >> 2)) * QS + nt * 16 + (qc & 3) * 4;
+            half8 vf;
+            const db_fp16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) db_fp16x4*)a0);
+            const db_fp16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) db_fp16x4*)a1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { vf[j] = (half_t)b0[j]; vf[4 + j] = (half_t)b1[j]; }
+            floatx4 o = o_acc[nt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= alpha;
+            o_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (has_next) {
+#pragma unroll
+            for (int it = 0; it < VITER; ++it) { kr_cur[it] = kr_nxt[it]; vr_cur[it] = vr_nxt[it]; }
+        }
+    }
+    // each query's own key (slot q_slot0 + row: written by the caller, not read back): one more online-softmax step on the wave
+    // that would take the next chunk.  o_acc[nt][r] = O[q = qc][d = 16 nt + 4 g + r]; P is rounded to fp16 like the MFMA operand.
+    if (wave == n_chunks % DB_WAVES) {
+        const bool vis = causal_row | tree_ok;
+        const float x = vis ? s_diag * scale_log2e : -INFINITY;
+        const float m_new = fmaxf(m_run, x);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        const float p = __builtin_amdgcn_exp2f(x - m_use);
+        const float ph = (float)(half_t)p;
+        l_run = l_run * alpha + (g == 0 ? p : 0.f);          // (l_run is summed over the 4 lane groups below)
+        m_run = m_new;
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            const half4 vv = *(const half4*)(v_s + qc * QS + nt * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o_acc[nt][r] = o_acc[nt][r] * alpha + ph * (float)vv[r];
+        }
+    }
+
+    // merge the waves
+    l_run = db_group4_sum(l_run);
+    __syncthreads();                                      // everyone is done with the K / V tiles
+    if (g == 0) { lds_ml[(wave * DB_BM + qc) * 2] = m_run; lds_ml[(wave * DB_BM + qc) * 2 + 1] = l_run; }
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt)
+        *(floatx4*)(lds_o + (wave * DB_BM + qc) * A::OSTR + nt * 16 + g * 4) = o_acc[nt];
+    __syncthreads();
+    {
+        constexpr int EPT = DB_BM * D / DB_THREADS;           // 2 (D = 64) or 4 (D = 128) output elements per thread
+        const int row = tid / (D / EPT), col = (tid % (D / EPT)) * EPT;
+        float mw[DB_WAVES], lw[DB_WAVES], mmax = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < DB_WAVES; ++w) {
+            mw[w] = lds_ml[(w * DB_BM + row) * 2];
+            lw[w] = lds_ml[(w * DB_BM + row) * 2 + 1];
+            mmax = fmaxf(mmax, mw[w]);
+        }
+        float denom = 0.f, wgt[DB_WAVES];
+#pragma unroll
+        for (int w = 0; w < DB_WAVES; ++w) {
+            wgt[w] = (mw[w] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[w] - mmax);
+            denom += lw[w] * wgt[w];
+        }
+        const float inv = denom > 0.f ? 1.0f / denom : 0.f;
+        half_t ov[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < DB_WAVES; ++w) a += lds_o[(w * DB_BM + row) * A::OSTR + col + e] * wgt[w];
+            ov[e] = (half_t)(a * inv);
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o_s[row * QS + col + e] = ov[e];
+    }
+    __syncthreads();
+}
 
 // KSW: k-steps (of 32) per wave: hidden = 256 KSW.
 template <int KSW, bool KV_ONLY>
@@ -198,17 +411,7 @@ __global__ void __launch_bounds__(DB_THREADS) draft_block_kernel(const DbParams 
     const int n_chunks = (n_keys + DB_BK - 1) / DB_BK;
     const half_t* kbase = P.k_layer + (size_t)head * P.m * DB_D;
     const half_t* vbase = P.v_layer + (size_t)head * P.m * DB_D;
-    auto issue_kv = [&](int chunk, u32x4 (&kr)[VITER], u32x4 (&vr)[VITER]) {
-        const int key0 = chunk * DB_BK;
-#pragma unroll
-        for (int it = 0; it < VITER; ++it) {
-            const int idx = it * 64 + lane;
-            const int r = idx / CPR, c = idx % CPR;
-            int row = key0 + r; if (row >= n_keys) row = n_keys - 1;
-            kr[it] = *(const u32x4*)(kbase + (size_t)row * DB_D + c * 8);
-            vr[it] = *(const u32x4*)(vbase + (size_t)row * DB_D + c * 8);
-        }
-    };
+    auto issue_kv = [&](int chunk, u32x4 (&kr)[VITER], u32x4 (&vr)[VITER]) { db_issue_kv<DB_D>(chunk, n_keys, lane, kbase, vbase, kr, vr); };
     if constexpr (!KV_ONLY && KV_EARLY) {
         if (wave < n_chunks) issue_kv(wave, kr_cur, vr_cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -292,175 +495,10 @@ __global__ void __launch_bounds__(DB_THREADS) draft_block_kernel(const DbParams 
         // ---- phase 3: attention of the tile's 16 queries over the cached keys + each query's own key ---------------------
         uint64_t* lds_bm = (uint64_t*)(db_lds + L::BM);
         float* lds_ml = (float*)(db_lds + L::ML);
-        half_t* lds_v = (half_t*)db_lds;
-        float* lds_o = (float*)db_lds;
-        const int words = P.words;
-        // the ancestor-bitmask rows of the 16 queries: [row][DB_MAX_WORDS]
-        if (tid < DB_BM * DB_MAX_WORDS) lds_bm[tid] = bm_word;
-        const int qc = r16;
-        const int qi_c = min(q0 + qc, P.q_len - 1);
-        const int slot = q_slot0 + qi_c;
-        const int tnode = slot - (gt - 1);
-        const bool causal_row = slot < gt;
-        const bool tree_ok = tnode < P.n_tree;
-
-        // Q fragments (B operand): lane (n = qc, g) holds Q[qc][32 s + 8 g .. +8]; this lane's share of q . k of its own row
-        half8 qf[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) qf[s] = *(const half8*)(q_s + qc * DB_QS + s * 32 + g * 8);
-        float s_diag = 0.f;
-        {
-            const half8 ka = *(const half8*)(k_s + qc * DB_QS + g * 16), kb = *(const half8*)(k_s + qc * DB_QS + g * 16 + 8);
-            const half8 qa = *(const half8*)(q_s + qc * DB_QS + g * 16), qb = *(const half8*)(q_s + qc * DB_QS + g * 16 + 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s_diag += (float)qa[e] * (float)ka[e];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s_diag += (float)qb[e] * (float)kb[e];
-            s_diag = db_group4_sum(s_diag);
-        }
-        __syncthreads();                                      // bitmask rows staged; the partial area is free for the K / V tiles
-        DB_STOP_AT(2, s_diag + (float)qf[0][0] + (float)qf[1][1] + (float)lds_bm[tid & 127])
-
-        float m_run = -INFINITY, l_run = 0.f;
-        floatx4 o_acc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o_acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-        half_t* my_v = lds_v + wave * L::KV_TILE;
-        half_t* my_k = my_v + DB_BK * DB_QS;
-        u32x4 kr_nxt[VITER], vr_nxt[VITER];
-        for (int ch = wave; ch < n_chunks; ch += DB_WAVES) {
-            const int key0 = ch * DB_BK;
-            const bool has_next = ch + DB_WAVES < n_chunks;
-            if (has_next) issue_kv(ch + DB_WAVES, kr_nxt, vr_nxt);
-#pragma unroll
-            for (int it = 0; it < VITER; ++it) {
-                const int idx = it * 64 + lane;
-                *(u32x4*)(my_k + (idx / CPR) * DB_QS + (idx % CPR) * 8) = kr_cur[it];
-                *(u32x4*)(my_v + (idx / CPR) * DB_QS + (idx % CPR) * 8) = vr_cur[it];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // S^T = K Q^T: lane (q = qc, g) receives keys key0 + 16 t + 4 g + r
-            floatx4 s_acc[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                floatx4 a = {0.f, 0.f, 0.f, 0.f};
-                half8 kf[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) kf[s] = *(const half8*)(my_k + (t * 16 + qc) * DB_QS + s * 32 + g * 8);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[s], qf[s], a, 0, 0, 0);
-                s_acc[t] = a;
-            }
-            float sv[8];
-            float cmax = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + t * 16 + g * 4 + r;
-                    float x = s_acc[t][r] * P.scale_log2e;
-                    const int j = key - (gt - 1);
-                    const uint64_t wv = lds_bm[qc * DB_MAX_WORDS + (((unsigned)j >> 6) < (unsigned)words ? (j >> 6) : 0)];
-                    const bool bit = (wv >> (j & 63)) & 1ull;
-                    const bool vis_tree = (key < gt) | (tree_ok & ((unsigned)j < (unsigned)P.n_tree) & bit);
-                    const bool vis = (key < n_keys) & (causal_row | vis_tree);     // (a committed-text row sees every key in front of it)
-                    x = vis ? x : -INFINITY;
-                    sv[t * 4 + r] = x;
-                    cmax = fmaxf(cmax, x);
-                }
-            cmax = db_group4_max(cmax);
-            const float m_new = fmaxf(m_run, cmax);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            half8 pf;
-            float psum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = __builtin_amdgcn_exp2f(sv[j] - m_use);
-                psum += p;
-                pf[j] = (half_t)p;
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const half_t* a0 = my_v + (0 * 16 + g * 4 + (qc >> 2)) * DB_QS + nt * 16 + (qc & 3) * 4;
-                const half_t* a1 = my_v + (1 * 16 + g * 4 + (qc >> 2)) * DB_QS + nt * 16 + (qc & 3) * 4;
-                half8 vf;
-                const db_fp16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) db_fp16x4*)a0);
-                const db_fp16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) db_fp16x4*)a1);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { vf[j] = (half_t)b0[j]; vf[4 + j] = (half_t)b1[j]; }
-                floatx4 o = o_acc[nt];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] *= alpha;
-                o_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o, 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (has_next) {
-#pragma unroll
-                for (int it = 0; it < VITER; ++it) { kr_cur[it] = kr_nxt[it]; vr_cur[it] = vr_nxt[it]; }
-            }
-        }
-        // each query's own key (slot q_slot0 + row: written above, not read back): one more online-softmax step on the wave
-        // that would take the next chunk.  o_acc[nt][r] = O[q = qc][d = 16 nt + 4 g + r]; P is rounded to fp16 like the MFMA operand.
-        if (wave == n_chunks % DB_WAVES) {
-            const bool vis = causal_row | tree_ok;
-            const float x = vis ? s_diag * P.scale_log2e : -INFINITY;
-            const float m_new = fmaxf(m_run, x);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            const float p = __builtin_amdgcn_exp2f(x - m_use);
-            const float ph = (float)(half_t)p;
-            l_run = l_run * alpha + (g == 0 ? p : 0.f);          // (l_run is summed over the 4 lane groups below)
-            m_run = m_new;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const half4 vv = *(const half4*)(v_s + qc * DB_QS + nt * 16 + g * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o_acc[nt][r] = o_acc[nt][r] * alpha + ph * (float)vv[r];
-            }
-        }
-
-        DB_STOP_AT(3, l_run + m_run + o_acc[0][0] + o_acc[1][1] + o_acc[2][2] + o_acc[3][3])
-        // merge the waves
-        l_run = db_group4_sum(l_run);
-        __syncthreads();                                      // everyone is done with the K / V tiles
-        if (g == 0) { lds_ml[(wave * DB_BM + qc) * 2] = m_run; lds_ml[(wave * DB_BM + qc) * 2 + 1] = l_run; }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-            *(floatx4*)(lds_o + (wave * DB_BM + qc) * L::OSTR + nt * 16 + g * 4) = o_acc[nt];
-        __syncthreads();
-        {
-            const int row = tid >> 5, col = (tid & 31) * 2;
-            float mw[DB_WAVES], lw[DB_WAVES], mmax = -INFINITY;
-#pragma unroll
-            for (int w = 0; w < DB_WAVES; ++w) {
-                mw[w] = lds_ml[(w * DB_BM + row) * 2];
-                lw[w] = lds_ml[(w * DB_BM + row) * 2 + 1];
-                mmax = fmaxf(mmax, mw[w]);
-            }
-            float denom = 0.f, wgt[DB_WAVES];
-#pragma unroll
-            for (int w = 0; w < DB_WAVES; ++w) {
-                wgt[w] = (mw[w] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[w] - mmax);
-                denom += lw[w] * wgt[w];
-            }
-            const float inv = denom > 0.f ? 1.0f / denom : 0.f;
-            half2v o2;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < DB_WAVES; ++w) a += lds_o[(w * DB_BM + row) * L::OSTR + col + e] * wgt[w];
-                o2[e] = (half_t)(a * inv);
-            }
-            *(half2v*)(o_s + row * DB_QS + col) = o2;
-        }
-        __syncthreads();
+        if (tid < DB_BM * DB_MAX_WORDS) lds_bm[tid] = bm_word;        // the ancestor-bitmask rows of the 16 queries
+        // (db_attend's first barrier orders these stores, and the reads of the K-partials above, before the K / V tiles)
+        db_attend<DB_D>(q_s, k_s, v_s, o_s, db_lds, lds_ml, lds_bm, kr_cur, vr_cur, kbase, vbase, n_keys, q0, P.q_len, q_slot0, gt,
+                        P.n_tree, P.words, P.scale_log2e, tid, wave);
 
         DB_STOP_AT(4, (float)o_s[tid])
         // ---- phase 4: this head's slice of o_proj ---------------------------------------------------------------------
@@ -538,5 +576,216 @@ extern "C" int sq_draft_attn_block_f16(const void* a_frag, const void* wqkv_frag
     { if (kv_only) db_go<K_, true>(P, n_tiles, st); else db_go<K_, false>(P, n_tiles, st); }
     if (ksw == 2) SQ_DB(2) else if (ksw == 3) SQ_DB(3) else SQ_DB(4)
 #undef SQ_DB
+    return sq_check_launch();
+}
+
+// ---- RoPE + KV write + tree attention of a forward whose rows never see each other, ANY draft (heads of 64 or 128) -----------
+// What it replaces: sq_rope_kv_write(_slabs)_f16 -> sq_tree_attention_f16, two dependent launches per layer (4.7 + 6.9 us on
+// the 1.3B draft of configuration D, 120 layer passes per speculation step; 5.0 + 5.6 us on the 68m draft when the block above
+// does not apply).  One workgroup per (query head, 16-row tile): the tile's q | k | v rows of that head are read from the
+// projection's output -- fp16 rows, or the fp32 split-K partials of sq_linear_ts_f16, summed in split order and rounded to fp16
+// like sq_rope_kv_write_slabs_f16 does --, rotated with the reference's fp16 roundings, the K / V rows go to their cache slots
+// (by the first query head of a KV group) and, together with the rotated queries, into LDS; db_attend runs the attention over
+// the cached keys + the row's own key; the output leaves as fp16 rows or as the fragment-major image of the o_proj operand.
+// Rounding points are those of the two launches; the attention's fp32 summation order differs (the own key is folded last).
+struct LaParams {
+    const half_t* qkv;        // [q_len][stride] fp16 rows, or null
+    const float* slab;        // [splits][q_len][stride] fp32 partials, or null
+    int splits, stride;
+    half_t* out;              // [q_len][H D] rows, or the fragment-major image (out_frag_mtp > 0)
+    int out_frag_mtp;
+    half_t* k_layer;          // [H_kv][M][D]
+    half_t* v_layer;
+    const half_t* cos_tab;
+    const half_t* sin_tab;
+    const int64_t* position_ids;
+    const int64_t* storage_ids;
+    const uint64_t* bitmask;
+    const int32_t* ctx;
+    int words, n_tree, q_slot0, gt;
+    int q_len, n_heads, h_kv, m, xcd_span;
+    float scale_log2e;
+};
+
+template <int D>
+struct LaLds {
+    using A = DbAtt<D>;
+    static constexpr int QKV = A::MAIN;                                        // q_s (later o_s), k_s, v_s: [16][D + 8] halves each
+    static constexpr int ML = QKV + 3 * DB_BM * A::QS * 2;
+    static constexpr int BM = ML + DB_WAVES * DB_BM * 8;
+    static constexpr int TOTAL = BM + DB_BM * DB_MAX_WORDS * 8;
+};
+
+template <int D, bool SLAB>
+__global__ void __launch_bounds__(DB_THREADS) level_attention_kernel(const LaParams P) {
+    using A = DbAtt<D>;
+    using L = LaLds<D>;
+    constexpr int QS = A::QS, VITER = A::VITER;
+    constexpr int RW = D / 64;                           // waves per rotating role: a thread owns one 8-chunk of the first half + its mate
+    extern __shared__ __attribute__((aligned(16))) unsigned char db_lds[];
+    half_t* q_s = (half_t*)(db_lds + L::QKV);
+    half_t* k_s = q_s + DB_BM * QS;
+    half_t* v_s = k_s + DB_BM * QS;
+    uint64_t* lds_bm = (uint64_t*)(db_lds + L::BM);
+    float* lds_ml = (float*)(db_lds + L::ML);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = (P.q_len + DB_BM - 1) / DB_BM;
+    const int grp = P.n_heads / P.h_kv;
+    int head, q_tile;
+    if (!att_decode_block(blockIdx.x, P.n_heads, P.h_kv, n_tiles, P.xcd_span, &head, &q_tile)) return;
+    const int q0 = q_tile * DB_BM;
+    const int kvh = head / grp;
+    int q_slot0 = P.q_slot0, gt = P.gt;
+    if (P.ctx) { q_slot0 = P.ctx[0]; gt = P.ctx[1]; }
+    if (gt < 1) gt = 1;
+    if (q_slot0 < 0) q_slot0 = 0;
+    if (q_slot0 > P.m) q_slot0 = P.m;
+    const int n_keys = q_slot0;
+    const half_t* kbase = P.k_layer + (size_t)kvh * P.m * D;
+    const half_t* vbase = P.v_layer + (size_t)kvh * P.m * D;
+
+    // the queries' ancestor-bitmask rows, this wave's first chunk of cached K / V rows: nothing here depends on q | k | v
+    if (tid < DB_BM * DB_MAX_WORDS) {
+        const int br = tid >> 3, bw = tid & 7;
+        const int tn = q_slot0 + min(q0 + br, P.q_len - 1) - (gt - 1);
+        uint64_t w = 0ull;
+        if (bw < P.words && tn >= 1 && tn < P.n_tree && P.bitmask) w = P.bitmask[(size_t)tn * P.words + bw];
+        lds_bm[tid] = w;
+    }
+    u32x4 kr_cur[VITER], vr_cur[VITER];
+    if (wave * DB_BK < n_keys) db_issue_kv<D>(wave, n_keys, lane, kbase, vbase, kr_cur, vr_cur);
+
+    // roles: waves [0, RW) rotate q, [RW, 2 RW) rotate k, [2 RW, 4 RW) move v (D = 64: waves 4-7 have no rows to move)
+    const size_t split_stride = (size_t)P.q_len * P.stride;
+    if (wave < 2 * RW) {
+        const bool is_k = wave >= RW;
+        const int lt = tid - (is_k ? RW * 64 : 0);
+        const int row = lt & 15, c = lt >> 4;                        // chunk c of the first half, 0 .. D / 16 - 1
+        const int ri = min(q0 + row, P.q_len - 1);
+        const int64_t pos = P.position_ids[ri];
+        const int64_t slot = P.storage_ids[ri];
+        const size_t src = (size_t)ri * P.stride + (size_t)(is_k ? P.n_heads + kvh : head) * D;
+        half8 x1, x2;
+        if (SLAB) {
+            const float* const sp[2] = {P.slab + src + c * 8, P.slab + src + D / 2 + c * 8};
+            floatx4 lo[2], hi[2];
+            slab_sum8<2>(sp, P.splits, split_stride, lo, hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x1[j] = (half_t)lo[0][j]; x1[4 + j] = (half_t)hi[0][j];
+                x2[j] = (half_t)lo[1][j]; x2[4 + j] = (half_t)hi[1][j];
+            }
+        } else {
+            x1 = *(const half8*)(P.qkv + src + c * 8);
+            x2 = *(const half8*)(P.qkv + src + D / 2 + c * 8);
+        }
+        const half8 c1 = *(const half8*)(P.cos_tab + (size_t)pos * D + c * 8);
+        const half8 c2 = *(const half8*)(P.cos_tab + (size_t)pos * D + D / 2 + c * 8);
+        const half8 s1 = *(const half8*)(P.sin_tab + (size_t)pos * D + c * 8);
+        const half8 s2 = *(const half8*)(P.sin_tab + (size_t)pos * D + D / 2 + c * 8);
+        half8 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // first half: x1*cos + (-x2)*sin ; second half: x2*cos + x1*sin -- every product and sum rounded to fp16
+            const half_t a1 = (half_t)((float)x1[e] * (float)c1[e]);
+            const half_t b1 = (half_t)((float)(-x2[e]) * (float)s1[e]);
+            o1[e] = (half_t)((float)a1 + (float)b1);
+            const half_t a2 = (half_t)((float)x2[e] * (float)c2[e]);
+            const half_t b2 = (half_t)((float)x1[e] * (float)s2[e]);
+            o2[e] = (half_t)((float)a2 + (float)b2);
+        }
+        half_t* dst_s = (is_k ? k_s : q_s) + row * QS;
+        *(half8*)(dst_s + c * 8) = o1;
+        *(half8*)(dst_s + D / 2 + c * 8) = o2;
+        if (is_k && head == kvh * grp && q0 + row < P.q_len && slot >= 0 && slot < P.m) {
+            half_t* dst = P.k_layer + ((size_t)kvh * P.m + slot) * D;
+            *(half8*)(dst + c * 8) = o1;
+            *(half8*)(dst + D / 2 + c * 8) = o2;
+        }
+    } else if (wave < 4 * RW) {
+        const int lt = tid - 2 * RW * 64;
+        const int row = lt & 15, c = lt >> 4;                        // chunk c of the row, 0 .. D / 8 - 1
+        const int ri = min(q0 + row, P.q_len - 1);
+        const int64_t slot = P.storage_ids[ri];
+        const size_t src = (size_t)ri * P.stride + (size_t)(P.n_heads + P.h_kv + kvh) * D + c * 8;
+        half8 x;
+        if (SLAB) {
+            const float* const sp[1] = {P.slab + src};
+            floatx4 lo[1], hi[1];
+            slab_sum8<1>(sp, P.splits, split_stride, lo, hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[j] = (half_t)lo[0][j]; x[4 + j] = (half_t)hi[0][j]; }
+        } else {
+            x = *(const half8*)(P.qkv + src);
+        }
+        *(half8*)(v_s + row * QS + c * 8) = x;
+        if (head == kvh * grp && q0 + row < P.q_len && slot >= 0 && slot < P.m)
+            *(half8*)(P.v_layer + ((size_t)kvh * P.m + slot) * D + c * 8) = x;
+    }
+    __syncthreads();
+
+    half_t* o_s = q_s;                                   // (every wave holds its query fragments before the merge writes here)
+    db_attend<D>(q_s, k_s, v_s, o_s, db_lds, lds_ml, lds_bm, kr_cur, vr_cur, kbase, vbase, n_keys, q0, P.q_len, q_slot0, gt,
+                 P.n_tree, P.words, P.scale_log2e, tid, wave);
+
+    // the tile's rows of this head: 16-byte chunks, row-major or fragment-major
+    if (tid < DB_BM * (D / 8)) {
+        const int row = tid / (D / 8), c = tid % (D / 8);
+        if (q0 + row < P.q_len) {
+            const half8 o = *(const half8*)(o_s + row * QS + c * 8);
+            const int ocol = head * D + c * 8;
+            half_t* dst = P.out_frag_mtp ? P.out + frag_chunk_offset(q0 + row, ocol >> 3, P.out_frag_mtp)
+                                         : P.out + (size_t)(q0 + row) * (P.n_heads * D) + ocol;
+            *(half8*)dst = o;
+        }
+    }
+}
+
+template <int D, bool SLAB>
+static void la_go(const LaParams& P, int blocks, hipStream_t st) {
+    using L = LaLds<D>;
+    auto kern = level_attention_kernel<D, SLAB>;
+    static bool attr_done[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
+        if (dev >= 0 && dev < 16) attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(DB_THREADS), L::TOTAL, st, P);
+}
+
+extern "C" int sq_level_attention_f16(const void* qkv, const float* qkv_slab, int splits, int qkv_stride, void* out, int out_frag,
+                                      void* k_layer, void* v_layer, const void* cos_tab, const void* sin_tab,
+                                      const int64_t* d_position_ids, const int64_t* d_storage_ids, int q_len, int n_heads,
+                                      int h_kv, int d, int m, float scale, int q_slot0, int gt, int n_tree,
+                                      const uint64_t* d_bitmask, int words, const int32_t* d_ctx, void* stream) {
+    if ((!qkv && !qkv_slab) || !out || !k_layer || !v_layer || !cos_tab || !sin_tab || !d_position_ids || !d_storage_ids)
+        return SQ_EINVAL;
+    if (q_len < 0 || n_heads <= 0 || h_kv <= 0 || n_heads % h_kv || m <= 0 || n_tree < 1 || n_tree > SQ_MAX_TREE) return SQ_EINVAL;
+    if (qkv_stride < (n_heads + 2 * h_kv) * d || (qkv_stride & 7)) return SQ_EINVAL;
+    if (qkv_slab && (splits < 1 || ((uintptr_t)qkv_slab & 15))) return SQ_EINVAL;
+    if (d != 64 && d != 128) return SQ_EUNSUPPORTED;
+    if (out_frag && ((n_heads * d) & 31)) return SQ_EUNSUPPORTED;
+    if (n_tree > 1 && (!d_bitmask || words < SQ_MASK_WORDS(n_tree) || words > DB_MAX_WORDS)) return SQ_EINVAL;
+    if (n_tree == 1) { words = 1; d_bitmask = nullptr; }
+    if (!d_ctx && (q_slot0 < 0 || q_slot0 > m || gt < 1)) return SQ_EINVAL;
+    if (q_len == 0) return SQ_OK;
+    LaParams P;
+    P.qkv = (const half_t*)qkv; P.slab = qkv_slab; P.splits = splits; P.stride = qkv_stride; P.out = (half_t*)out;
+    P.out_frag_mtp = out_frag ? (q_len + 15) / 16 : 0;
+    P.k_layer = (half_t*)k_layer; P.v_layer = (half_t*)v_layer; P.cos_tab = (const half_t*)cos_tab;
+    P.sin_tab = (const half_t*)sin_tab; P.position_ids = d_position_ids; P.storage_ids = d_storage_ids;
+    P.bitmask = d_bitmask; P.ctx = d_ctx; P.words = words; P.n_tree = n_tree; P.q_slot0 = q_slot0; P.gt = gt < 1 ? 1 : gt;
+    P.q_len = q_len; P.n_heads = n_heads; P.h_kv = h_kv; P.m = m;
+    P.scale_log2e = scale * 1.4426950408889634f;
+    const int n_tiles = (q_len + DB_BM - 1) / DB_BM;
+    P.xcd_span = h_kv < 8 ? att_xcd_span(n_heads, h_kv, n_tiles) : 0;
+    const int blocks = att_grid_blocks(n_heads, h_kv, n_tiles, P.xcd_span);
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 128) { if (qkv_slab) la_go<128, true>(P, blocks, st); else la_go<128, false>(P, blocks, st); }
+    else          { if (qkv_slab) la_go<64, true>(P, blocks, st);  else la_go<64, false>(P, blocks, st); }
     return sq_check_launch();
 }

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "sq_norm_linear_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sq_draft_attn_block_f16": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i,
                                      _vp, _i, _vp, _i, _vp]),
+    "sq_level_attention_f16": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _i,
+                                    _vp, _vp]),
     "sq_ar_workspace_bytes": (C.c_size_t, [_i, C.c_size_t, C.c_size_t]),
     "sq_ar_alloc": (_i, [C.POINTER(_vp), C.c_size_t]),
     "sq_ar_free": (_i, [_vp]),

@@ -495,6 +495,36 @@ class HipOps:
               "sq_draft_attn_block_f16")
         return slab
 
+    def level_attention(self, qkv, out, k_layer, v_layer, cos, sin, position_ids, storage_ids, n_heads, h_kv, d, scale, q_slot0, gt,
+                        n_tree, bitmask=None, ctx=None, out_frag=False, qkv_slab=None):
+        """RoPE + KV write + tree attention in one launch for rows that never see each other (csrc/draft_block.hip).
+        qkv: [q, (H + 2 H_kv) D] fp16 rows, or qkv_slab = (fp32 slab, splits, q_len, n_cols): split-K partials."""
+        _need(out, torch.float16, "out"); _need(k_layer, torch.float16, "k_layer"); _need(v_layer, torch.float16, "v_layer")
+        _need(cos, torch.float16, "cos"); _need(sin, torch.float16, "sin")
+        _need(position_ids, torch.int64, "position_ids"); _need(storage_ids, torch.int64, "storage_ids")
+        m = k_layer.shape[-2]
+        words = 0
+        if bitmask is not None:
+            _need(bitmask, torch.int64, "bitmask")
+            words = bitmask.shape[1]
+        if qkv_slab is not None:
+            slab, splits, q_len, stride = qkv_slab
+            _need(slab, torch.float32, "slab")
+            assert slab.numel() >= splits * q_len * stride
+            src, sl = None, slab.data_ptr()
+        else:
+            _need(qkv, torch.float16, "qkv", contiguous=False)
+            assert qkv.dim() == 2 and qkv.stride(1) == 1
+            q_len, stride, splits = qkv.shape[0], qkv.stride(0), 0
+            src, sl = qkv.data_ptr(), None
+        assert position_ids.numel() >= q_len and storage_ids.numel() >= q_len
+        check(self.lib.sq_level_attention_f16(src, sl, int(splits), int(stride), out.data_ptr(), 1 if out_frag else 0,
+                                              k_layer.data_ptr(), v_layer.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                              position_ids.data_ptr(), storage_ids.data_ptr(), int(q_len), int(n_heads), int(h_kv),
+                                              int(d), int(m), float(scale), int(q_slot0), int(gt), int(n_tree), _ptr(bitmask),
+                                              int(words), _ptr(ctx), self._stream()), "sq_level_attention_f16")
+        return out
+
     def add_rmsnorm_slabs(self, slab, splits, residual, sum_out, weight, out, eps, out_frag=False):
         """x = h(sum of the split-K partials); sum_out = x + residual; out = RMSNorm(sum_out) * weight
         (out None: add only)."""

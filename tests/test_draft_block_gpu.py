@@ -248,3 +248,63 @@ def test_draft_forward_block_on_equals_off():
     _rows_close(k0[1], k1[1], 16.0)
     top0, top1 = l0.topk(8, dim=-1).indices.sort(dim=-1).values, l1.topk(8, dim=-1).indices.sort(dim=-1).values
     assert (top0 == top1).float().mean() > 0.97
+
+
+# ---- level attention: RoPE + KV write + tree attention in one launch, any head dim --------------------------------------------
+LA_CASES = [
+    # H, Hkv, D, M, gt, level sizes, level, splits
+    (16, 16, 128, 384, 140, [1, 8, 20, 35], 2, 2),       # configuration D's draft (Sheared-LLaMA-1.3B: 16 heads of 128), 20-row level
+    (16, 16, 128, 384, 140, [1, 8, 20, 35], 3, 0),       # 35 rows (3 tiles), fp16 rows instead of partials
+    (32, 32, 128, 1024, 700, [1, 64, 64], 1, 2),         # configuration E's draft (7B dims): 64-row level, long prefix
+    (12, 12, 64, 384, 130, [1, 8, 34, 40, 45], 2, 3),    # 68m dims (what the fused block covers; the generic kernel must agree too)
+    (8, 2, 128, 512, 200, [1, 30, 100, 116, 120], 3, 4), # GQA 4:1, 8 bitmask words, 116 rows
+    (4, 1, 64, 256, 64, [1, 16], 0, 0),                  # one row (the root), one KV head
+]
+
+
+@pytest.mark.parametrize("H,Hkv,D,M,gt,sizes,level,splits", LA_CASES)
+def test_level_attention_matches_two_launches(ops, H, Hkv, D, M, gt, sizes, level, splits):
+    rng = np.random.RandomState(H * 3 + D + level)
+    succ, first = level_tree(rng, sizes)
+    n = len(succ)
+    bm = dev(O.bitmask_from_successors(succ).view(np.int64))
+    a, b = int(first[level]), int(first[level + 1])
+    q_len, q_slot0 = b - a, gt - 1 + a
+    stride = (H + 2 * Hkv) * D
+    cos, sin = O.rope_tables(D, 1024)
+    pos = dev(np.full(q_len, gt + level - 1, np.int64))
+    sid = dev((q_slot0 + np.arange(q_len)).astype(np.int64))
+    k = rng.randn(Hkv, M, D).astype(np.float16); v = rng.randn(Hkv, M, D).astype(np.float16)
+    k[:, q_slot0:] = 0; v[:, q_slot0:] = 0
+    if splits:
+        slab = dev((rng.randn(splits, q_len, stride) * 0.7).astype(np.float32))
+    else:
+        rows = dev(rng.randn(q_len, stride).astype(np.float16))
+    outs = []
+    for fused in (False, True):
+        kk, vv = dev(k), dev(v)
+        for frag in (False, True):
+            out = torch.zeros(ops.frag_shape(q_len, H * D) if frag else (q_len, H * D), dtype=torch.float16, device=DEV)
+            if fused:
+                ops.level_attention(None if splits else rows, out, kk, vv, dev(cos), dev(sin), pos, sid, H, Hkv, D, D ** -0.5,
+                                    q_slot0, gt, n, bitmask=bm, out_frag=frag,
+                                    qkv_slab=(slab, splits, q_len, stride) if splits else None)
+            else:
+                q_rot = torch.empty((H, q_len, D), dtype=torch.float16, device=DEV)
+                if splits:
+                    ops.rope_kv_write_slabs(slab, splits, stride, q_rot, kk, vv, dev(cos), dev(sin), pos, sid, H, Hkv, D)
+                else:
+                    ops.rope_kv_write(rows, q_rot, kk, vv, dev(cos), dev(sin), pos, sid, H, Hkv, D)
+                ops.tree_attention(q_rot, kk, vv, out, q_slot0 + q_len, D ** -0.5, q_slot0=q_slot0, gt=gt, n_tree=n, bitmask=bm,
+                                   out_frag=frag)
+            outs.append((fused, frag, out, kk, vv))
+    torch.cuda.synchronize()
+    ref = {f: (o, kk, vv) for fu, f, o, kk, vv in outs if not fu}
+    for fu, f, o, kk, vv in outs:
+        if not fu:
+            continue
+        ro, rk, rv = ref[f]
+        assert torch.equal(kk, rk) and torch.equal(vv, rv)              # same rounding points, same split order: bit-exact rows
+        assert torch.isfinite(o).all()
+        err = float((o.float() - ro.float()).abs().max())
+        assert err <= 4e-3, err                                          # P rounded to fp16 against another running maximum
