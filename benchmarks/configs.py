@@ -24,7 +24,23 @@ def step_weight_bytes(loop, gm):
         return per_layer * len(W.layers) + W.lm_head.numel() * 2
     n_draft_forwards = (len(gm.levels) if hasattr(gm, "levels") else 0) + 1
     t, d = model_bytes(loop.target), model_bytes(loop.draft)
-    return dict(target=t, draft=d, draft_forwards=n_draft_forwards, total=t + d * n_draft_forwards)
+    # The draft forward over the LAST tree level stops after its last layer's KV write (Tree/step_graph.py::KV_ONLY_LAST_LEVEL:
+    # leaves have no children to sample): it streams neither the last layer's o / gate_up / down nor lm_head.
+    skipped = 0
+    try:
+        from sequoia_amd.Engine.ts_linear import MAX_ROWS
+        from sequoia_amd.Tree.step_graph import KV_ONLY_LAST_LEVEL
+        m = loop.draft.engine.model
+        levels = list(gm.levels) if hasattr(gm, "levels") else []
+        last_rows = int(getattr(levels[-1], "total", 0)) if levels else 0
+        if KV_ONLY_LAST_LEVEL and getattr(m, "ts", None) is not None and levels and 0 < last_rows <= MAX_ROWS \
+                and getattr(loop, "pipelined", True):
+            sh = m.ts.shapes
+            skipped = m.weights.lm_head.numel() * 2 + sum((2 if sh[n][2] else 1) * sh[n][0] * sh[n][1] * 2 for n in ("o", "gate_up", "down"))
+    except Exception:
+        skipped = 0
+    return dict(target=t, draft=d, draft_forwards=n_draft_forwards, draft_skipped_last_level=skipped,
+                total=t + d * n_draft_forwards - skipped)
 
 
 def tp_bytes_per_rank(wb):

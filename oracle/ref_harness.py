@@ -19,7 +19,7 @@ What is supplied from the OUTSIDE is the environment those lines name, nothing i
     functions they capture (shim 5); the drop-in's are its own;
   * a torch-function mode that maps the literal "cuda:0" of the harness lines to the CPU, and `torch.cuda.synchronize` -> no-op.
 
-    python oracle/ref_harness.py reference out.npz [seed]   # subprocess side: the reference's classes (needs /root/reference)
+    python oracle/ref_harness.py reference out.npz [seed [growmap]]   # subprocess side: the reference's classes (needs /root/reference)
     run_dropin(npz)                                         # in-process side: sequoia_amd.dropin + the oracle adapter
 """
 from __future__ import annotations
@@ -135,8 +135,8 @@ def noise_seed(seed, prompt):
     return 7000 + 131 * seed + prompt
 
 
-def harness_args(seed):
-    return types.SimpleNamespace(model="draft", target="target", dataset="synthetic", growmap=os.path.join(REF, GROWMAP), start=0, end=3,
+def harness_args(seed, growmap=None):
+    return types.SimpleNamespace(model="draft", target="target", dataset="synthetic", growmap=os.path.join(REF, growmap or GROWMAP), start=0, end=3,
                                  T=TEMP, P=TOP_P, M=M_LEN, seed=seed, Mode="greedy", offloading=False)
 
 
@@ -151,7 +151,8 @@ def run_harness(code, ns, seed):
 
 
 # ---- (a) the reference's classes ---------------------------------------------------------------------------------------
-def run_reference(out_path, seed):
+def run_reference(out_path, seed, growmap=None):
+    growmap = growmap or GROWMAP
     sys.path.insert(0, HERE)
     import gen_golden as GG
     from oracle import ops_np
@@ -200,7 +201,7 @@ def run_reference(out_path, seed):
         return torch.tensor([tok], dtype=torch.long)
 
     ns = dict(torch=torch, time=time, np=np, random=__import__("random"), tqdm=lambda it, total=None: it, print=print,
-              DataLoader=object, args=harness_args(seed), dataloader=batches, SpecTree=SpySpecTree,
+              DataLoader=object, args=harness_args(seed, growmap), dataloader=batches, SpecTree=SpySpecTree,
               GraphInferenceEngine=engine_factory(R["GIE"], R["IE"], R["MM"].LlamaForCausalLM_FI, "draft", sd_d),
               GraphInferenceEngineTG=engine_factory(R["GIETG"], R["IETG"], R["MM"].LlamaForCausalLM_TG, "target", sd_t),
               OffloadEngine=None,
@@ -219,17 +220,28 @@ def run_reference(out_path, seed):
         arrays[f"prompt{i}/input_ids"] = b["input_ids"].numpy()
         arrays[f"prompt{i}/labels"] = b["labels"].numpy()
     arrays["bonus_u24"] = u24
-    keep_residuals = os.environ.get("SEQUOIA_HARNESS_RESIDUALS", "0") == "1"
+    # The committed text is append-only, so the tokens verify() call j returned are the first verify_len[j] tokens of its
+    # prompt's final sequence -- checked here, then stored that way (a record is a few KB).
+    final = {}
+    for p, toks, step, res in log:
+        assert p not in final or np.array_equal(final[p], toks[:len(final[p])]), "the committed text changed retroactively"
+        final[p] = toks
+    for p, toks in final.items():
+        arrays[f"prompt{p}/final"] = toks
+    arrays["verify_prompt"] = np.array([p for p, *_ in log], dtype=np.int64)
+    arrays["verify_len"] = np.array([len(t) for _, t, *_ in log], dtype=np.int64)
+    arrays["verify_step"] = np.array([st for _, _, st, _ in log], dtype=np.int64)
+    # the distribution every bonus token was drawn from, sparse (peaked rows: a handful of tokens carry mass): what proves a
+    # boundary draw when another arithmetic picks the neighbouring token
     for j, (p, toks, step, res) in enumerate(log):
-        arrays[f"verify{j}/tokens"] = toks
-        arrays[f"verify{j}/prompt"] = np.int64(p)
-        arrays[f"verify{j}/step"] = np.int64(step)
-        if keep_residuals and res is not None:     # the distribution the bonus token was drawn from (live runs: proves a boundary draw)
-            arrays[f"verify{j}/residual"] = res
-    g = torch.load(os.path.join(REF, GROWMAP), weights_only=False)
+        if res is not None:
+            nz = np.nonzero(np.nan_to_num(res.astype(np.float32)) > 0)[0]
+            arrays[f"verify{j}/res_ids"] = nz.astype(np.int32)
+            arrays[f"verify{j}/res_p"] = res[nz].astype(np.float16)
+    g = torch.load(os.path.join(REF, growmap), weights_only=False)
     meta = dict(seed=seed, value=float(value), n_verify=len(log), n_prompts=len(batches), dims=list(TINY), vocab=VOCAB, M=M_LEN,
                 successors=g["Successors"], gain=GAIN, share=SHARE, branch=BRANCH,
-                T=TEMP, top_p=TOP_P, growmap=GROWMAP, lines=code["lines"], seconds=round(dt, 1), torch=torch.__version__,
+                T=TEMP, top_p=TOP_P, growmap=growmap, lines=code["lines"], seconds=round(dt, 1), torch=torch.__version__,
                 weight_checksums=checks, accepted_per_verify=[int(len(t[1])) for t in log])
     arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(out_path, **arrays)
@@ -241,6 +253,46 @@ def load_record(path):
     z = np.load(path)
     meta = json.loads(bytes(z["meta_json"]).decode())
     return z, meta
+
+
+def record_tokens(z, j):
+    """The tokens verify() call j handed to the harness loop."""
+    return z[f"prompt{int(z['verify_prompt'][j])}/final"][:int(z["verify_len"][j])]
+
+
+def record_residual(z, j, vocab):
+    """Dense fp16 distribution the bonus token of call j was drawn from (None when the step was terminal)."""
+    if f"verify{j}/res_ids" not in z.files:
+        return None
+    p = np.zeros(vocab, dtype=np.float16)
+    p[z[f"verify{j}/res_ids"]] = z[f"verify{j}/res_p"]
+    return p
+
+
+def classify_run(z, meta, log):
+    """Compare a run's verify log [(prompt, tokens), ...] with a record.  Returns ("identical", None), or
+    ("boundary", (call, distance)): the runs agree on every token up to ONE bonus draw, whose recorded uniform lies `distance`
+    (probability mass under the reference's own residual) from the interval of the token this run drew, or
+    ("differs", (call, why)): anything else."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import cdf_interval_distance
+    n = meta["n_verify"]
+    for j, (p, toks) in enumerate(log):
+        if j >= n:
+            return "differs", (j, "more verify calls than the reference made")
+        ref = record_tokens(z, j)
+        if p == int(z["verify_prompt"][j]) and np.array_equal(toks, ref):
+            continue
+        if p != int(z["verify_prompt"][j]) or len(toks) != len(ref) or not np.array_equal(toks[:-1], ref[:-1]):
+            return "differs", (j, "the accepted paths differ")
+        res = record_residual(z, j, meta["vocab"])
+        if res is None:
+            return "differs", (j, "no residual recorded")
+        u = int(z["bonus_u24"][p * STEPS_PER_PROMPT + int(z["verify_step"][j])])
+        return "boundary", (j, cdf_interval_distance(res, int(toks[-1]), u))
+    if len(log) != n:
+        return "differs", (len(log), "fewer verify calls than the reference made")
+    return "identical", None
 
 
 def run_dropin(z, meta, device="cpu", growmap=None, code=None):
@@ -289,7 +341,7 @@ def run_dropin(z, meta, device="cpu", growmap=None, code=None):
                 log.append((state["prompt"], out[0].clone().cpu().numpy()))
                 return out
 
-        args = harness_args(seed)
+        args = harness_args(seed, meta["growmap"])
         ns = dict(torch=torch, time=time, np=np, random=__import__("random"), tqdm=lambda it, total=None: it, print=print,
                   DataLoader=object, args=args, dataloader=batches, SpecTree=SpySpecTree,
                   GraphInferenceEngine=factory(GraphInferenceEngine, "draft"),
@@ -319,6 +371,6 @@ def run_dropin(z, meta, device="cpu", growmap=None, code=None):
 if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "reference":
         sys.path.insert(0, REPO)
-        run_reference(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 11)
+        run_reference(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 11, sys.argv[4] if len(sys.argv) > 4 else None)
     else:
         raise SystemExit(__doc__)

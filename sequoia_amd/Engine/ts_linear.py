@@ -30,6 +30,9 @@ from ..ops import get_ops
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLAN_FILE = os.path.join(_PKG, "ts_plans_gfx950.json")
 MAX_ROWS = 144
+# the 129-row build (8 MFMA row tiles + the extra row on the vector ALU, csrc/ts_linear.hip) is what allows 4 gate+up units per
+# workgroup at 129 rows; SEQUOIA_TS_TAIL=0 (read by the library too) rounds 129 rows up to 9 row tiles, which take <= 3 units
+TAIL_ROWS = 129 if (os.environ.get("SEQUOIA_TS_TAIL") or "1")[0] != "0" else 128
 ENABLED = os.environ.get("SEQUOIA_TS_LINEAR", "1") != "0"
 # Tensor-parallel jobs replicate the draft model, the samplers and the verifier on every rank and rely on bit-identical
 # results across ranks (no broadcast of decisions).  Launch plans picked by per-rank timing would break that (a
@@ -81,7 +84,7 @@ def candidates(n_out: int, k: int, silu: bool, m: int, allow_split: bool = False
                 out.append((tiles, splits))
     wide = 6 if m > 64 else 4
     if silu:
-        add(n_out // 16, 4 if m <= 129 else 3, (1,))         # fused epilogue: <= 4 gate+up units (8 MFMA column tiles; 3 beyond 129 rows:
+        add(n_out // 16, 4 if m <= TAIL_ROWS else 3, (1,))   # fused epilogue: <= 4 gate+up units (8 MFMA column tiles; 3 beyond 129 rows:
         #                                                      129 = 8 MFMA row tiles + the extra row on the vector ALU, csrc/ts_linear.hip)
         if allow_split:
             add(2 * n_out // 16, wide, (2, 3, 4))
@@ -241,7 +244,7 @@ class TsLinearSet:
                     # 8-tile + extra-row build (<= 8 SwiGLU column tiles, <= 6 plain), 130-144 rows the 9-tile build (<= 6 / <= 6)
                     # -- a plan measured at 129 rows must still launch for a 144-row chunk of a prefill
                     units = n_out // 16
-                    max_u = (4 if q_len <= 129 else 3) if silu else (8 if q_len <= 128 else 6)
+                    max_u = (4 if q_len <= TAIL_ROWS else 3) if silu else (8 if q_len <= 128 else 6)
                     if int(rec[1]) == 1 and -(-units // int(rec[0])) > max_u:
                         rec = (-(-units // max_u), 1)
                 p[name] = None if rec == "torch" else (int(rec[0]), int(rec[1]))

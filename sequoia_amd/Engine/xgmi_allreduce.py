@@ -78,6 +78,14 @@ class XgmiAllReduce:
             raise XgmiCollectiveTimeout(f"rank {self.rank}: an xGMI collective gave up waiting for a peer (status bits {bits}: {what}); "
                                         "its result is invalid -- everything decoded after it would be too")
 
+    def _pre(self):
+        """Every collective looks at the pinned fault word before it launches (a host read, no device access, legal inside a
+        capture): once a wait of this workspace has given up, every later wait polls ONCE (csrc/allreduce.hip: the sticky
+        status word) and the kernels continue on whatever their areas hold -- a faulted workspace is dead, and a caller that
+        never polls raise_on_fault() (a direct TPEngine / XgmiAllReduce user) must not get partial sums at full speed
+        (ADVICE r05).  The raise comes one call late at the earliest: the word is written by the kernel that timed out."""
+        self.check_fault()
+
     def clear_fault(self):
         """Tests that provoke a timeout on purpose."""
         if self.fault is not None:
@@ -250,6 +258,7 @@ class XgmiAllReduce:
     # ---- the call ---------------------------------------------------------------------------------------------
     def __call__(self, x: torch.Tensor, blocks: int = 0) -> torch.Tensor:
         """In-place sum over the ranks of a contiguous fp16 tensor (numel % 8 == 0, numel <= max_elems)."""
+        self._pre()
         if x.dtype != torch.float16 or not x.is_contiguous() or x.device.type != "cuda":
             raise TypeError("xgmi all-reduce: contiguous fp16 tensor on the device")
         native.check(self.lib.sq_allreduce_sum_f16(x.data_ptr(), x.numel(), self.rank, self.world, self._table, self.max_elems,
@@ -260,6 +269,7 @@ class XgmiAllReduce:
     def reduce_slabs(self, slab: torch.Tensor, splits: int, out: torch.Tensor, blocks: int = 0) -> torch.Tensor:
         """out[n] (fp16) = sum over the ranks of h(sum_s slab[s][n]): the all-reduce of a split-K row-parallel projection
         straight from its fp32 partials (slab: [>= splits * n] fp32, n = out.numel())."""
+        self._pre()
         n = out.numel()
         assert slab.dtype == torch.float32 and slab.numel() >= splits * n and out.dtype == torch.float16 and out.is_contiguous()
         native.check(self.lib.sq_allreduce_sum_slabs_f16(slab.data_ptr(), int(splits), out.data_ptr(), n, self.rank, self.world,
@@ -277,6 +287,7 @@ class XgmiAllReduce:
                            out_frag: bool, splits: int = 0) -> torch.Tensor:
         """x <- x + all-reduce(partial); out = RMSNorm(x) * weight (row-major or fragment-major), one launch.
         partial: fp16 rows [rows, hidden] (splits == 0) or the fp32 split-K slab [splits][rows][hidden]."""
+        self._pre()
         rows, hidden = x.shape
         assert x.dtype == torch.float16 and x.is_contiguous() and weight.dtype == torch.float16 and out.dtype == torch.float16
         if splits:
@@ -295,6 +306,7 @@ class XgmiAllReduce:
 
     def gather_cols(self, slice_: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """[rows, v] per rank -> [rows, world v] on every rank (rank r's columns at [r v, (r + 1) v))."""
+        self._pre()
         rows, v = slice_.shape
         # The per-(peer, block) "read" handshake protects the bytes a block overwrites in the peer's image only while the slice
         # WIDTH is the one of the previous gather (offsets in the image are i W v + R v: another v moves every row).  The product

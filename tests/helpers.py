@@ -20,6 +20,9 @@ ESCAPES: list = []
 # measured distance between this build's logits and the reference's recorded ones, beyond 4 fp16 ulps of the value --
 # printed in the session summary so that the tolerance is a number next to its evidence
 LOGIT_EXCESS: dict = {}
+# tests/test_dropin_harness_gpu.py: per tree size (identical, total, distances of the boundary draws) of the UNSCREENED records of
+# the reference's harness replayed on this GPU
+HARNESS_RATE: dict = {}
 
 
 def note_escape(label, margin):

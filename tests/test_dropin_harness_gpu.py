@@ -137,18 +137,14 @@ def test_utils_factories_match_oracle():
     assert abs(float(res.float().sum()) - 1.0) < 2e-2
 
 
-@pytest.mark.parametrize("seed", [24, 25, 28])
-def test_reference_harness_record_replays_on_gpu(seed):
-    """tests/golden/harness_simulation_fast_<seed>.npz are runs of the reference's own `simulation_fast` source on the
-    reference's classes (oracle/ref_harness.py compiles tests/testbed.py:35-40,45-95,250-285,297-298 from the file's AST;
-    tests/test_reference_harness_cpu.py executes the same lines on the drop-in with the numpy oracle, token-identical).  The
-    reference's file cannot travel to the GPU box, so here its body is RE-TYPED on the record's inputs -- seeded weights,
-    prompts, noise and bonus uniforms pinned as on the CPU -- and the HIP library must hand the harness loop the reference's
-    tokens in every verify call."""
-    import numpy as np
+def _replay_record_on_gpu(path):
+    """The reference's harness body (tests/testbed.py:45-95 + set-up :250-285) RE-TYPED on a record's inputs -- the file itself
+    cannot travel to the GPU box; tests/test_reference_harness_cpu.py executes the reference's own lines on the drop-in --
+    with seeded weights, prompts, noise and bonus uniforms pinned as oracle/ref_harness.py pins them.  Returns the harness's
+    value and the log [(prompt, tokens)] of what every verify() handed to the loop."""
     from oracle import ref_harness as RH
     import sequoia_amd.dropin as dropin
-    z, meta = RH.load_record(os.path.join(REPO, "tests", "golden", f"harness_simulation_fast_{seed}.npz"))
+    z, meta = RH.load_record(path)
     dropin.install(force=True)
     try:
         from Engine.Engine import GraphInferenceEngine, GraphInferenceEngineTG
@@ -192,7 +188,7 @@ def test_reference_harness_record_replays_on_gpu(seed):
         position_ids = torch.zeros(M).long().to("cuda:0")
         num_decoding_steps = num_large_model_steps = 0
         u24 = z["bonus_u24"]
-        j = 0
+        log = []
         with torch.no_grad():
             for step in range(meta["n_prompts"]):
                 input_ids = torch.from_numpy(z[f"prompt{step}/input_ids"])[..., :128]
@@ -214,10 +210,7 @@ def test_reference_harness_record_replays_on_gpu(seed):
                 while input_ids.shape[1] < 256 and terminate is False:
                     spectree.construct_grow_map()
                     valid_tokens, draft_kv_len, target_kv_len, terminate = spectree.verify()
-                    assert j < meta["n_verify"] and int(z[f"verify{j}/prompt"]) == step
-                    assert np.array_equal(valid_tokens.cpu().numpy(), z[f"verify{j}/tokens"]), \
-                        f"verify call {j} (prompt {step}): tokens differ from the reference's harness run"
-                    j += 1
+                    log.append((step, valid_tokens.cpu().numpy().copy()))
                     num_decoding_steps += valid_tokens.shape[0] - input_ids.shape[1]
                     num_large_model_steps += 1
                     input_ids = valid_tokens.unsqueeze(0)
@@ -226,7 +219,46 @@ def test_reference_harness_record_replays_on_gpu(seed):
                 torch.cuda.synchronize()
                 draft_model.clear_kv()
                 target_model.clear_kv()
-        assert j == meta["n_verify"]
-        assert num_decoding_steps / num_large_model_steps == meta["value"]
+        return z, meta, num_decoding_steps / max(num_large_model_steps, 1), log
     finally:
         dropin.uninstall()
+
+
+@pytest.mark.parametrize("seed", [24, 25, 28])
+def test_reference_harness_record_replays_on_gpu(seed):
+    """tests/golden/harness_simulation_fast_<seed>.npz: runs of the reference's own `simulation_fast` source on the reference's
+    classes (oracle/ref_harness.py) whose CPU drop-in run is token-identical; the HIP library must hand the harness loop the
+    reference's tokens in every verify call too."""
+    from oracle import ref_harness as RH
+    z, meta, value, log = _replay_record_on_gpu(os.path.join(REPO, "tests", "golden", f"harness_simulation_fast_{seed}.npz"))
+    assert RH.classify_run(z, meta, log) == ("identical", None)
+    assert value == meta["value"]
+
+
+@pytest.mark.parametrize("tree", ["4x8", "s128"])
+def test_unscreened_reference_harness_seeds_on_gpu(tree):
+    """20 runs of the reference's harness per tree size, seeds 100-119 TAKEN AS THEY COME (oracle/gen_harness_golden.py): how
+    many does this GPU reproduce token for token?  Nothing excuses a miss except ONE bonus draw at a CDF boundary of the
+    reference's own residual distribution (the uniform within 2 % of mass of the interval of the token drawn here: the residual
+    is a normalised difference of nearly equal fp16 probabilities, one ulp of either moves its boundaries).  The counts are
+    printed in the session summary (tests/conftest.py)."""
+    import glob
+    import helpers
+    from oracle import ref_harness as RH
+    paths = sorted(glob.glob(os.path.join(REPO, "tests", "golden", f"harness_unscreened_{tree}_*.npz")))
+    assert len(paths) >= 20
+    identical, boundary = 0, []
+    for path in paths:
+        z, meta, value, log = _replay_record_on_gpu(path)
+        kind, info = RH.classify_run(z, meta, log)
+        if kind == "identical":
+            identical += 1
+            assert value == meta["value"]
+            continue
+        assert kind == "boundary", f"{os.path.basename(path)}: {kind} {info}"
+        call, dist = info
+        assert dist <= 2e-2, (os.path.basename(path), call, dist)
+        boundary.append((os.path.basename(path), call, dist))
+        helpers.note_escape(f"{os.path.basename(path)} verify call {call}: bonus draw at a CDF boundary", dist)
+    helpers.HARNESS_RATE[tree] = (identical, len(paths), [round(d, 5) for _, _, d in boundary])
+    assert identical >= len(paths) // 2, (identical, boundary)

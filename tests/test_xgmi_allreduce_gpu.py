@@ -220,7 +220,13 @@ def _lonely_worker(rank, world, port, out_dir):
             XA.raise_on_fault()
         except XA.XgmiCollectiveTimeout:
             raised = 1
-        np.save(os.path.join(out_dir, "lonely.npy"), np.array([ar.status(), fault, raised]))
+        # a caller that never polls raise_on_fault() is stopped by the NEXT collective on the dead workspace
+        refused = 0
+        try:
+            ar(x)
+        except XA.XgmiCollectiveTimeout:
+            refused = 1
+        np.save(os.path.join(out_dir, "lonely.npy"), np.array([ar.status(), fault, raised, refused]))
         ar.clear_fault()
     dist.barrier()
     ar.close()
@@ -231,8 +237,8 @@ def test_missing_peer_times_out_instead_of_hanging(tmp_path, monkeypatch):
     monkeypatch.setenv("SEQUOIA_AR_SPIN_LIMIT", "200000")        # ~0.3 s instead of the production bound of a few seconds
     port = 34700 + (os.getpid() % 1500)
     mp.spawn(_lonely_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    status, fault, raised = (int(v) for v in np.load(tmp_path / "lonely.npy"))
-    assert status & 1 == 1 and fault != 0 and raised == 1
+    status, fault, raised, refused = (int(v) for v in np.load(tmp_path / "lonely.npy"))
+    assert status & 1 == 1 and fault != 0 and raised == 1 and refused == 1
 
 
 @pytest.mark.parametrize("name,world,fused_norm", [("E_64x2", 2, "1"), ("E_70b_w2", 2, "1"), ("E_64x2", 4, "1"), ("demo4", 4, "1"),
