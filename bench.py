@@ -249,10 +249,11 @@ def main():
             draft.clear_kv(); target.clear_kv()
             autoreg = AutoregressiveLoop(cfg, target, device, prompts).run(3)
             autoreg["speedup"] = (new_tok / secs) / autoreg["tokens_per_s"]
-        cpu = None
+        cpu, cpu_keep = None, {}
         if not args.no_cpu_baseline and world == 1:
             try:
-                cpu = cpu_baseline(cfg, args.cpu_steps, args.pair)
+                cpu_keep = {}
+                cpu = cpu_baseline(cfg, args.cpu_steps, args.pair, keep_engines=cpu_keep)
                 cpu.pop("tokens", None)
             except Exception as e:  # the baseline is a report, never the measured path
                 cpu = dict(value=None, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
@@ -305,10 +306,27 @@ def main():
         if (not args.no_other_configs and world == 1 and args.config == "B" and not args.growmap and args.pair == "calibrated"
                 and not args.sync_loop and not args.no_graphs):
             other = {}
-            try:
-                other["C"], _ = run_other_config("C", args, device, prompts, engines=(draft, target), steps=args.other_steps)
-            except Exception as e:
-                other["C"] = dict(error=f"{type(e).__name__}: {e}")
+            for oc in ("A", "C"):                 # the same 68m / 7B engines on BASELINE.json configs[0] (2-chain) and configs[2] (8x8 greedy)
+                try:
+                    other[oc], _ = run_other_config(oc, args, device, prompts, engines=(draft, target), steps=args.other_steps)
+                except Exception as e:
+                    other[oc] = dict(error=f"{type(e).__name__}: {e}")
+            if not args.no_cpu_baseline and "error" not in other["A"]:
+                # configs[0] is the case the reference runs on a CPU: the port's time for it on this host beside the GPU's
+                try:
+                    from sequoia_amd.growmap import GrowMap as _GM
+                    from sequoia_amd.harness import MODELS as _M
+                    eng = cpu_keep.get("engines")
+                    if eng is not None:
+                        eng[0].clear_kv(); eng[1].clear_kv()
+                    cb = cpu_baseline(dict(_M["A"]), n_steps=3, pair=args.pair,
+                                      engines=None if eng is None else (eng[0], eng[1], _GM.load(_M["A"]["growmap"])))
+                    other["A"]["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "steps_per_s",
+                                                                          "prefill_step_s", "steady_step_s")}
+                    other["A"]["gpu_over_cpu_port"] = (other["A"]["value_steady"] / cb["value"]) if cb.get("value") else None
+                except Exception as e:
+                    other["A"]["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}")
+            cpu_keep.clear()
             import gc
             for oc, osteps in (("D", args.other_steps), ("E", min(args.other_steps, 12))):
                 if oc == "E" and args.no_config_e:

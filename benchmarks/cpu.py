@@ -13,7 +13,7 @@ from sequoia_amd.harness import build, load_prompts
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=False):
+def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=False, keep_engines=None):
     """The CPU path timed on this box's host cores: the same host loop with the reference's PyTorch op sequences
     restated for CPU tensors (oracle/ops_torch_cpu.py; verification on the numpy oracle) and PyTorch CPU GEMMs, fp16
     like the reference, on a bounded sample: n_steps
@@ -38,6 +38,8 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
         t0 = time.perf_counter()
         draft, target, gm = engines if engines is not None else build(cfg, "cpu", pair)
         build_s = time.perf_counter() - t0
+        if isinstance(keep_engines, dict):            # the caller times another configuration on the same CPU engines (config A)
+            keep_engines["engines"] = (draft, target)
         from sequoia_amd.Tree.GreedyTree import GreedyTree
         from sequoia_amd.Tree.SpecTree import SpecTree
         from sequoia_amd.Tree._native_tree import COMMIT_ORDER
@@ -98,8 +100,9 @@ def cpu_baseline(cfg, n_steps=3, pair="calibrated", engines=None, numpy_ops=Fals
             pass
         return dict(value=(tok_per_step / best_s) if n_steady else None, unit="tokens/s", cores=best_thr,
                     kind="port", commit_order=COMMIT_ORDER,
-                    sample=f"{len(step_s)} speculation steps of prompt 0, config {cfg['draft']} -> {cfg['target']}, the "
-                           f"reference's torch op sequences on CPU fp16 tensors; step 0 (with the 255-token target prefill) "
+                    sample=f"{len(step_s)} speculation steps of prompt 0, config {cfg['draft']} -> {cfg['target']}, growmap "
+                           f"{cfg.get('growmap')} ({gm.size} nodes), the "
+                           f"reference's torch op sequences on CPU fp16 tensors; step 0 (with the {127 + gm.size}-token target prefill) "
                            f"{step_s[0]:.1f} s, then {n_steady} steady steps: one per thread count of {sweep}, two more at the "
                            f"fastest; median seconds / step by thread count { {t: round(v, 2) for t, v in mean_by_thr.items()} }; "
                            f"value = mean tokens/step of the steady steps / the MEDIAN of the {len(by_thr.get(best_thr, []))} steps at "

@@ -20,6 +20,8 @@ def _sync(device):
         torch.cuda.synchronize()
 
 MODELS = {
+    # BASELINE.json configs[0]: the reference's own CPU-runnable plumbing case (2-node chain)
+    "A": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="2-chain", mode="stochastic", M=384),
     "B": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="A100-CNN-68m-7b-stochastic",
               mode="stochastic", M=384),
     "C": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="8x8-tree", mode="greedy", M=384),

@@ -41,9 +41,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
                                 "from fresh random inputs or live traces of the reference on new seeds)")
     for label, m in esc:
         terminalreporter.write_line(f"  {label}: margin {m:.3e}")
-    for tree, (same, total, dists) in sorted(getattr(helpers, "HARNESS_RATE", {}).items()):
-        terminalreporter.write_line(f"reference-harness seeds token-identical on this GPU (unscreened, tree {tree}): {same} / {total}"
-                                    + (f"; the other {total - same}: ONE bonus draw at a CDF boundary each, distances {dists}" if total > same else ""))
+    for tree, (same, total, expl, unexpl) in sorted(getattr(helpers, "HARNESS_RATE", {}).items()):
+        terminalreporter.write_line(f"reference-harness runs token-identical on this GPU (UNSCREENED seeds, tree {tree}): {same} / {total}; "
+                                    f"{len(expl)} part from the reference's run at ONE decision that two fp16 ulps per logit (or an exact tie) "
+                                    f"flip: {expl}; {len(unexpl)} otherwise: {unexpl}")
     if helpers.LOGIT_EXCESS:
         terminalreporter.write_line("logit distance to the reference's recorded logits beyond 4 fp16 ulps (draft / target / tolerance):")
         for (name, layers), (dd, dt, tol) in sorted(helpers.LOGIT_EXCESS.items()):
