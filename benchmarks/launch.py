@@ -90,6 +90,8 @@ def _tp_child(n: int, args, extra_env: dict, timeout_s: int = 0) -> dict:
                         "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
     env["SEQUOIA_TS_EXCLUSIVE"] = "1"          # one copy of the 70B shard per rank
     env.update(extra_env)
+    if getattr(args, "selftest", False):       # the model-free launcher test exercises this child job too (CPU, gloo)
+        cmd.append("--selftest")
     import signal
     from types import SimpleNamespace
     # own session: on a timeout the whole tree (launcher + ranks) is killed by process group, nothing keeps a GPU
@@ -140,11 +142,23 @@ def selftest(args, world, rank):
         ranks = dist.get_world_size()
     else:
         steps_all = float(args.steps)
+    tp = getattr(args, "config", "B") == "E" and world > 1
+    extra = {}
+    if tp:
+        # the tensor-parallel child job's shape: one all-reduce over the group, reported the way allreduce_timing() reports it
+        t = torch.ones(8)
+        dist.all_reduce(t)
+        extra["allreduce"] = dict(kind=dist.get_backend(), xgmi_status=None, sum_ok=bool((t == world).all()),
+                                  xgmi_self_check="not running on the xGMI kernels: launcher selftest (no device)")
     if rank == 0:
-        print(json.dumps(dict(metric="accepted tokens/sec", value=None, unit="tokens/s", n_gpus=world, steps=args.steps,
-                              warmup=args.warmup, ms_per_step=secs / args.steps * 1e3, higher_is_better=True,
-                              scaling="weak", vs_baseline=None, dtype="f16", data="synthetic", selftest=True,
-                              rccl_ranks=ranks, steps_per_s=steps_all / secs,
-                              config=dict(workload="launcher selftest (no model)", parallelism="replicas" if world > 1 else "single"))))
+        line = dict(metric="accepted tokens/sec", value=None, unit="tokens/s", n_gpus=world, steps=args.steps,
+                    warmup=args.warmup, ms_per_step=secs / args.steps * 1e3, higher_is_better=True,
+                    scaling="strong" if tp else "weak", vs_baseline=None, dtype="f16", data="synthetic", selftest=True,
+                    rccl_ranks=ranks, steps_per_s=steps_all / secs,
+                    config=dict(workload="launcher selftest (no model)",
+                                parallelism=f"tp{world}" if tp else ("replicas" if world > 1 else "single")), **extra)
+        if world > 1 and not tp and not getattr(args, "no_tp_extra", False):
+            line["tp_70b"] = tp_extra(world, args)      # the child job, its timeout / retry wrapper and the trimming of its line
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

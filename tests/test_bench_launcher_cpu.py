@@ -29,6 +29,19 @@ def test_gpus_2_spawns_two_ranks():
     assert abs(line["steps_per_s"] * line["ms_per_step"] / 1e3 - 2.0) < 1e-6      # whole-job rate = 2 ranks' steps / max time
 
 
+def test_tp_child_job_reports_what_its_collectives_ran_on():
+    """The replica headline's `tp_70b` block (configuration E tensor-parallel over the same N ranks, a child job with a
+    timeout): N ranks really formed the group (`rccl_ranks` == N == `n_gpus`), the run says at top level which transport the
+    collectives used (`allreduce_kind`, `xgmi_self_check`, `collectives_env`) -- what a first real multi-GPU run is read by."""
+    line = _run(["--gpus", "2", "--backend", "gloo"])
+    tp = line["tp_70b"]
+    assert "error" not in tp, tp
+    assert tp["n_gpus"] == 2 and tp["rccl_ranks"] == 2 and tp["scaling"] == "strong" and tp["config"]["parallelism"] == "tp2"
+    assert tp["allreduce_kind"] == "gloo" and tp["collectives_env"] == "xgmi"
+    assert tp["xgmi_self_check"].startswith("not running on the xGMI kernels")
+    assert tp["allreduce"]["sum_ok"] is True
+
+
 def test_gpus_1_stays_in_process():
     line = _run(["--gpus", "1"])
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["config"]["parallelism"] == "single"

@@ -43,7 +43,7 @@ for stage in "$@"; do
     timeout 1200 python -m pytest tests/test_step_pipeline_gpu.py -m gpu -q -k "V32k_seq128 or B_topp09 or D_13b_w4 or E_70b_w2 or L_S256_v32k or config_b or eos" > $O/tests_overlap.log 2>&1
     grep -n "passed\|failed\|rror" $O/tests_overlap.log | tail -8 ;;
   pmc_ts)      # FETCH / WRITE / MFMA passes of the projection kernel at the shipped plans + tree attention -> profiles/r06_pmc.json
-    bash tools/pmc_r05.sh > $O/pmc_ts_run.log 2>&1; tail -14 $O/pmc_ts_run.log
+    bash tools/pmc_r06.sh > $O/pmc_ts_run.log 2>&1; tail -14 $O/pmc_ts_run.log
     [ -f gpurun_out/r06/pmc_ts/r06_pmc.json ] && cp gpurun_out/r06/pmc_ts/r06_pmc.json $O/pmc.json && cp $O/pmc.json profiles/r06_pmc.json ;;
   tsplans)     # the shipped 128-row 7B plans and the 129-row 70B plans, standalone (tools/ts_bench)
     for spec in "7b:128:qkv:128:2" "7b:128:o+res:64:4" "7b:128:gate_up+silu:230:1" "7b:128:down+res:64:4" "7b:128:o+res:128:2" "7b:128:down+res:128:2" "7b:128:down+res:32:8" "70b:129:qkv:128:2" "70b:129:o+res:128:2" "70b:129:down+res:128:4" "70b:129:down+res:64:8" "13b:64:qkv:120:2"; do
