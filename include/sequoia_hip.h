@@ -461,9 +461,11 @@ int sq_allreduce_add_rmsnorm_f16(const void* slab, int splits, const void* in_ro
                                  int out_frag, int rows, int hidden, float eps, int rank, int world, void* const* ws,
                                  size_t max_elems, void* stream);
 
+#ifdef SEQUOIA_BUILD_PROBES
 /* ---- f1: RMSNorm folded into the projection that consumes it (small draft models) ------------------------------
  * EXPERIMENTAL: measured 8 % slower than the unfused launch sequence on MI355X (profiles/r03_draft_fused_not_adopted.md);
- * opt-in (SEQUOIA_DRAFT_FUSED=1), kept for the measurement and its tests; the signature may change or disappear.
+ * NOT part of the default surface since round 6 (built with SEQUOIA_BUILD_PROBES=1 only, csrc/draft_fused.hip; opt-in at run
+ * time with SEQUOIA_DRAFT_FUSED=1), kept for the measurement and its tests; the signature may change or disappear.
  * out = epilogue( (RMSNorm(x) * norm_weight) . w^T ) for m <= 48 rows and k in {256, 512, 768, 1024} (the 68m / 160m drafts): every
  * workgroup normalises the whole activation block itself into LDS, so the separate norm launch in front of
  * q/k/v_proj, gate/up_proj and lm_head (Engine/Llama_modules.py:282-288,341-346; Engine/Llama_model.py:280-283)
@@ -476,6 +478,7 @@ int sq_allreduce_add_rmsnorm_f16(const void* slab, int splits, const void* in_ro
 int sq_norm_linear_f16(const void* x, const int64_t* d_ids, const void* embed, int vocab, void* x_out,
                        const void* norm_weight, float eps, const void* w_frag, void* out, int ldo, int m, int n_out,
                        int k, int swiglu, int tiles, void* stream);
+#endif
 
 /* ---- f1: the attention half of a small draft model's decoder layer in ONE launch ---------------------------------
  * For forwards whose rows never attend to each other -- the draft forward over ONE tree level (Tree/SpecTree.py:87-134:

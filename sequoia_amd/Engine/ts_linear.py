@@ -377,7 +377,7 @@ SMALL_MAX_ROWS, SMALL_MAX_HIDDEN = 48, 1024
 
 def small_fused_ok(model, ts: "TsLinearSet", q_len: int) -> bool:
     d = model.dims
-    return (SMALL_FUSED and q_len <= SMALL_MAX_ROWS and d.hidden_size <= SMALL_MAX_HIDDEN and model.reduce_fn is None
+    return (SMALL_FUSED and hasattr(get_ops().lib, "sq_norm_linear_f16") and q_len <= SMALL_MAX_ROWS and d.hidden_size <= SMALL_MAX_HIDDEN and model.reduce_fn is None
             and model.gather_logits_fn is None and not ts.exclusive and ts.shapes["down"][1] % 32 == 0
             and d.tp_world == 1)
 

@@ -10,11 +10,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libsequoia_hip.so")
-SOURCES = ["kv_ops.hip", "sampler.hip", "verify.hip", "tree_attention.hip", "fused_ops.hip", "ts_linear.hip", "allreduce.hip", "draft_fused.hip", "draft_block.hip"]
-# measurement aids (tools/prefetch_probe.py) stay out of the product library: SEQUOIA_BUILD_PROBES=1 adds them
+SOURCES = ["kv_ops.hip", "sampler.hip", "verify.hip", "tree_attention.hip", "fused_ops.hip", "ts_linear.hip", "allreduce.hip", "draft_block.hip"]
+# measurement aids (tools/prefetch_probe.py) and measured-negative experiments (draft_fused.hip: RMSNorm inside the projection,
+# profiles/r03_draft_fused_not_adopted.md) stay out of the product library: SEQUOIA_BUILD_PROBES=1 adds them
 PROBES = os.environ.get("SEQUOIA_BUILD_PROBES", "0") == "1"
 if PROBES:
-    SOURCES = SOURCES + ["ts_probe.hip"]
+    SOURCES = SOURCES + ["ts_probe.hip", "draft_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"] + (["-DSEQUOIA_BUILD_PROBES"] if PROBES else [])
 # per-source additions.  ts_linear: keep the MFMA accumulators in VGPRs -- with the AGPR form the register
 # allocator permutes the 48-128 accumulator registers on every trip of the ring loop (72 v_accvgpr_* moves

@@ -73,7 +73,6 @@ PROTOTYPES = {
     "sq_add_rmsnorm_frag_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sq_silu_mul_frag_f16": (_i, [_vp, _vp, _i, _i, _vp]),
     "sq_silu_mul_slabs_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
-    "sq_norm_linear_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sq_draft_attn_block_f16": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i,
                                      _vp, _i, _vp, _i, _vp]),
     "sq_level_attention_f16": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _i,
@@ -103,6 +102,7 @@ class SequoiaNativeError(RuntimeError):
 
 # measurement aids outside the library's default surface (include/sequoia_hip.h: #ifdef SEQUOIA_BUILD_PROBES)
 PROBE_PROTOTYPES = {
+    "sq_norm_linear_f16": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sq_linear_ts_prefetch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 

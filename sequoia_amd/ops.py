@@ -449,6 +449,9 @@ class HipOps:
                     x_out=None):
         """out = epilogue((RMSNorm(x) * norm_weight) . w^T), the norm computed inside the projection (m <= 48, k <= 1024).
         ids / embed: first layer, x = embed[ids] (x_out receives the residual stream)."""
+        if not hasattr(self.lib, "sq_norm_linear_f16"):
+            raise native.SequoiaNativeError("sq_norm_linear_f16 is an experiment outside the default library: build with "
+                                            "SEQUOIA_BUILD_PROBES=1 (csrc/draft_fused.hip)")
         _need(norm_weight, torch.float16, "norm_weight"); _need(w_frag, torch.float16, "w_frag")
         _need(out, torch.float16, "out", contiguous=swiglu)
         if ids is not None:

@@ -10,6 +10,14 @@ import torch
 from oracle import ops_np as O
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _needs_experiment_build():
+    """csrc/draft_fused.hip is outside the default library since round 6 (measured negative; SEQUOIA_BUILD_PROBES=1 builds it)."""
+    from sequoia_amd import native
+    if not hasattr(native.load(), "sq_norm_linear_f16"):
+        pytest.skip("sq_norm_linear_f16 not built (SEQUOIA_BUILD_PROBES=1)")
 DEV = "cuda:0"
 
 

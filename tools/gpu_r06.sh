@@ -91,6 +91,17 @@ import json;d=json.loads(open('$O/bench_replicas2.json').read().strip().splitlin
   traces)      # every end-to-end replay of the reference's traces (host-driven and whole-step graphs)
     timeout 2400 python -m pytest tests/test_e2e_gpu.py tests/test_step_pipeline_gpu.py tests/test_baselines_gpu.py tests/test_probe_gpu.py -m gpu -q > $O/tests_traces.log 2>&1
     grep -n "passed\|failed\|rror\|margin" $O/tests_traces.log | tail -12 | cut -c1-300 ;;
+  components)  # the 128-row 7B projections at the shipped plans, production build and TS_DBG experiment builds (tools/ts_dbg_build.sh):
+    #              which part of a launch is the weight stream, the activation ingest, the MFMAs, the merge + stores
+    for bits in 0 1 2 3 4 32 24 36; do
+      for spec in "qkv:128:2" "o+res:64:4" "gate_up+silu:230:1" "down+res:64:4"; do
+        IFS=: read shape tiles splits <<< "$spec"
+        if [ $bits = 0 ]; then lib=""; else lib="LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/tools/_dbg/$bits"; fi
+        echo -n "TS_DBG=$bits $shape ${tiles}x$splits: "
+        env $lib TS_ARCH=7b TS_ONLY="$shape" TS_TILES=$tiles TS_SPLITS=$splits timeout 120 $GRAFT_REPO_ROOT/tools/ts_bench 128 2>&1 | grep "us " | head -1
+      done
+    done > $O/ts_components.log 2>&1
+    cat $O/ts_components.log | cut -c1-200 ;;
   kernels)
     timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q > $O/tests_kernels.log 2>&1; tail -3 $O/tests_kernels.log ;;
   tests)
