@@ -77,6 +77,11 @@ for stage in "$@"; do
     timeout 1500 python -m pytest tests/test_xgmi_allreduce_gpu.py -m gpu -q > $O/tests_xgmi.log 2>&1; tail -3 $O/tests_xgmi.log | cut -c1-300 ;;
   tp2)         # configuration E tensor-parallel with two ranks on the ONE GPU (functional: xGMI kernels over hipIpc-mapped buffers)
     SEQUOIA_TS_EXCLUSIVE=1 SEQUOIA_BENCH_ONE_DEVICE=1 timeout 900 python bench.py --gpus 2 --config E --backend gloo --steps 8 --warmup 2 --no-cpu-baseline --no-autoregressive > $O/benchE_tp2.json 2> $O/benchE_tp2.err; line $O/benchE_tp2.json; tail -2 $O/benchE_tp2.err | cut -c1-300 ;;
+  tp8)         # configuration E at TP = 8 with all eight ranks on the ONE GPU (functional: the real 70B shard shapes, xGMI kernels over
+    #              hipIpc-mapped buffers, whole-step graphs; the times are time-slicing, not link measurements)
+    SEQUOIA_TS_EXCLUSIVE=1 SEQUOIA_BENCH_ONE_DEVICE=1 timeout 1500 python bench.py --gpus 8 --config E --backend gloo --steps 6 --warmup 2 --no-cpu-baseline --no-autoregressive > $O/benchE_tp8.json 2> $O/benchE_tp8.err; line $O/benchE_tp8.json; tail -2 $O/benchE_tp8.err | cut -c1-300
+    python -c "
+import json;d=json.loads(open('$O/benchE_tp8.json').read().strip().splitlines()[-1]);a=d.get('allreduce') or {};print('n_gpus',d.get('n_gpus'),'rccl_ranks',d.get('rccl_ranks'),'allreduce',{k:a.get(k) for k in ('kind','xgmi_status','xgmi_self_check','xgmi_us','workspace')},'step_loop',(d.get('config') or {}).get('step_loop'))" ;;
   replicas2)   # the driver's N > 1 command with two replica ranks on the one GPU (gloo), incl. the tensor-parallel child job
     SEQUOIA_BENCH_ONE_DEVICE=1 timeout 1200 python bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_replicas2.json 2> $O/bench_replicas2.err; line $O/bench_replicas2.json; python -c "
 import json;d=json.loads(open('$O/bench_replicas2.json').read().strip().splitlines()[-1]);t=d.get('tp_70b') or {};print('n_gpus',d.get('n_gpus'),'rccl_ranks',d.get('rccl_ranks'),'tp_70b',{k:t.get(k) for k in ('value','ms_per_step','allreduce_kind','xgmi_status','error','steady_ms_per_step')})" ;;
