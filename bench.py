@@ -36,7 +36,7 @@ sys.path.insert(0, REPO)
 from sequoia_amd.harness import MODELS, Loop, build, load_prompts  # noqa: E402
 from benchmarks.configs import run_other_config, step_weight_bytes, tp_bytes_per_rank  # noqa: E402
 from benchmarks.cpu import cpu_baseline  # noqa: E402
-from benchmarks.kernels import kernel_rooflines, pmc_lookup, pmc_northstar  # noqa: E402
+from benchmarks.kernels import in_loop_duration, kernel_rooflines, pmc_lookup, pmc_northstar  # noqa: E402
 from benchmarks.launch import allreduce_timing, selftest, spawn_ranks, tp_extra  # noqa: E402
 
 
@@ -207,6 +207,10 @@ def main():
                     time_per_step_us=per_step[dom] * 1e6)
         if traffic_note:
             roof["traffic_note"] = traffic_note
+        loop_us, loop_file = in_loop_duration(dom, d.get("plan"), gm.size) if args.config == "B" else (None, None)
+        if loop_us is not None:
+            # the same kernel between its real neighbours (rocprofv3 kernel trace of the loop alone, committed under profiles/)
+            roof.update(avg_launch_us_in_loop=loop_us, frac_in_loop=d["bytes"] / (loop_us * 1e-6) / 1e9 / peak_hbm, in_loop_record=loop_file)
         kernels = {k: dict(avg_us=v["seconds"] * 1e6, gbps=v["bytes"] / v["seconds"] / 1e9,
                            frac=v["bytes"] / v["seconds"] / 1e9 / peak_hbm, algorithmic_bytes=v["bytes"],
                            launches_per_step=v["launches_per_step"], per_step_us=per_step[k] * 1e6,

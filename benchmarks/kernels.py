@@ -215,6 +215,28 @@ def kernel_rooflines(cfg, loop, device):
     return res
 
 
+def in_loop_duration(dom, plan=None, rows=128):
+    """Average duration of the dominant projection kernel INSIDE the speculation loop, from the newest committed rocprofv3
+    kernel-trace summary of the loop alone (profiles/r*_bench_kernel_stats_loop_only.md, `tools/gpu_r0N.sh loop`): the
+    `roofline` object times the kernel on an isolated launch loop with HIP events; this is the same kernel between its real
+    neighbours.  Returns (avg_us, file) or (None, None).  Only the SwiGLU projection is unambiguous in
+    the summary (the one `ts_linear_kernel<MT, NT, D, true>` instantiation with the row count's MT)."""
+    import glob
+    import re
+    if dom != "linear_ts_gate_up":
+        return None, None
+    mt = (rows + 15) // 16
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench_kernel_stats_loop_only.md")), reverse=True):
+        best = None
+        for line in open(path):
+            m = re.match(r"\| `void ts_linear_kernel<(\d+), (\d+), (\d+), true>\(TsParams\)` \| (\d+) \| ([\d.]+) \| ([\d.]+) \|", line)
+            if m and int(m.group(1)) == mt and (best is None or float(m.group(5)) > best[0]):
+                best = (float(m.group(5)), float(m.group(6)))
+        if best is not None:
+            return best[1], os.path.basename(path)
+    return None, None
+
+
 def source_sha(*names):
     """sha256[:16] over kernel sources: a PMC record is only valid for the code it was measured on."""
     import hashlib

@@ -143,6 +143,9 @@ class _GraphRunner:
 
     def replay(self, input_ids, storage_ids, position_ids, attn_mask=None, tree: TreeContext | None = None,
                borrow: bool = False):
+        # a captured forward always produces its logits: TreeContext.need_logits = False (KV rows only) is a property of the
+        # device-driven step's own launch sequence (Tree/step_graph.py), not of a graph runner
+        assert tree is None or tree.need_logits, "graph runners compute logits: need_logits = False is not supported here"
         kv = self.engine.kv_cache
         ops = get_ops()
         fast = (hasattr(ops, "stage_inputs") and input_ids.is_contiguous() and storage_ids.is_contiguous()

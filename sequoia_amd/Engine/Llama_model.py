@@ -372,6 +372,7 @@ class _LlamaForCausalLM:
         KV cache (causal prefix / tree mask by slot: a tree node's ancestors have smaller ids, i.e. sit in the same or an
         earlier chunk), so the result equals the one-pass forward up to accumulation order.  Legal inside a captured step
         (verify forwards of the 193- / 256- / 512-node growmaps on a target in exclusive mode)."""
+        assert tree is None or tree.need_logits, "the chunked forward returns logits: need_logits = False is not supported here"
         outs = []
         for r0 in range(0, q_len, TS_MAX_ROWS):
             r1 = min(q_len, r0 + TS_MAX_ROWS)

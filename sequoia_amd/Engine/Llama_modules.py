@@ -51,7 +51,11 @@ class TreeContext:
     stage: tuple | None = None
     # False: the caller needs this forward's KV rows only, not its logits -- the draft forward over the LAST tree level
     # (its nodes are leaves: no child is ever sampled from their rows, Tree/SpecTree.py:103).  The tall-skinny forward
-    # then stops after the last layer's RoPE + KV write (Engine/ts_linear.py::forward_ts) and returns None.
+    # then stops after the last layer's RoPE + KV write (Engine/ts_linear.py::forward_ts) and returns None.  Consequence for
+    # readers of the tree's buffers: the `draft_logits` rows (and sampler statistics) of LEAF nodes are not refreshed by a
+    # device-driven step -- they hold an earlier step's values; nothing on the path reads them (no child is sampled from a leaf,
+    # the verifier reads the draft rows of internal nodes only).  Honoured by forward_ts alone; the graph runners
+    # (Engine/Engine.py::_GraphRunner) and the chunked forward assert it is True.
     need_logits: bool = True
     # True: no query of this forward may see another query's key (only its own) -- the draft forward over ONE tree level
     # (the new nodes of a level are siblings / cousins, none is another's ancestor: Tree/SpecTree.py:87-134).  Small drafts
