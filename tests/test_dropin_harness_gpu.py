@@ -150,9 +150,11 @@ def _explain_divergence(z, meta, j, spectree, snap, prev_len, got):
       ("sampler", x)    the reference accepted a token this step's tree never drafted for that parent: x = |ln key_ref - ln
                         key_min| of the sampling keys log(u) / q (key_min: the smallest key drafted); limit 4 d -- or the
                         token's q sits at the fp16 underflow boundary (key -inf on one side only): x = |ln q - ln 2^-25|;
-      ("tie", 0)        the parent has fewer tokens of non-zero fp16 draft probability than children: both the reference's
-                        token and the last token drafted here carry the key -inf -- an exact tie whose order torch.topk leaves
-                        unspecified (this package: lowest token id first);
+      ("tie", 0)        an order torch leaves unspecified decided it: (a) an exact tie of fp16 sampling keys on the accepted path
+                        (torch.topk; here the lowest token id first) -- also the -inf keys of a parent with fewer non-zero-
+                        probability tokens than children --, after which the tied tokens sit on swapped sibling nodes with
+                        subtrees of other shapes; (b) the nucleus cut inside a class of exactly equal target logits (the
+                        reference's unstable CPU sort; here by token id) containing a drafted child's token;
       ("unexplained", why, 0)."""
     import numpy as np
     from helpers import cdf_interval_distance
@@ -180,14 +182,23 @@ def _explain_divergence(z, meta, j, spectree, snap, prev_len, got):
     got_nodes = [int(x) - (gt - 1) for x in lr[SQ_RESULT_INTS:SQ_RESULT_INTS + int(lr[SQ_RES_N_TREE])]]
     # walk the tree along the reference's accepted tokens, replaying the accept tests on this GPU's logits
     node, depth = 0, 0
+    key_tie = False          # the path passed a parent where the accepted token's sampling key ties EXACTLY with a sibling's
     while True:
         kids = succ[node]
         want_tok = ref_acc[depth] if depth < len(ref_acc) else None
         want = next((c for c in kids if int(tokens_pre[gt - 1 + c]) == want_tok), None) if want_tok is not None else None
         have = got_nodes[depth] if depth < len(got_nodes) else None
+        if want is not None and len(kids) > 1:
+            rand_ = spectree.rand[node].cpu().numpy()[None]
+            keys_ = O.sample_keys(draft[node][None], rand_, T)[0]
+            kt = [keys_[int(tokens_pre[gt - 1 + c])] for c in kids]
+            key_tie = key_tie or sum(1 for k_ in kt if k_ == keys_[want_tok]) > 1
         if want_tok is not None and want is None:
-            if not kids:
-                return "unexplained", "the reference accepted below a leaf of this tree", 0
+            if key_tie or not kids:
+                # an exact tie of fp16 sampling keys further up the accepted path: torch.topk leaves the order inside the tie
+                # unspecified (here: lowest token id first), the tied tokens sit on swapped sibling nodes, and the growmap
+                # gives those nodes subtrees of other shapes -- the reference's next accepted token has no node here
+                return ("tie", 0.0, 0.0) if key_tie else ("unexplained", "the reference accepted below a leaf of this tree", 0)
             rand = spectree.rand[node].cpu().numpy()[None]
             keys = O.sample_keys(draft[node][None], rand, T)[0].astype(np.float64)
             kmin = min(float(keys[int(tokens_pre[gt - 1 + c])]) for c in kids)
@@ -207,6 +218,21 @@ def _explain_divergence(z, meta, j, spectree, snap, prev_len, got):
             node, depth = want, depth + 1
             continue
         # the walks part below `node`: replay its accept tests (Tree/SpecTree.py:136-157) up to the first child either side took
+        raw = snap.get("target_raw")
+        if raw is not None:
+            # the nucleus cut (utils.py:65-77) inside a class of exactly equal logits: WHICH of the equal tokens stay is decided
+            # by torch's unstable CPU sort in the reference, by token id here; a drafted child whose token
+            # is in that class has p > 0 on one side and p = 0 on the other
+            rw = raw[node].astype(np.float32)
+            kept = np.isfinite(target[node])
+            if kept.any() and (~kept).any():
+                vmin = rw[kept].min()
+                cls = rw == vmin
+                toks_ = {int(tokens_pre[gt - 1 + c]) for c in (want, have) if c is not None}
+                if (cls & ~kept).any() and any(cls[t_] for t_ in toks_):
+                    return "tie", 0.0, 0.0
+        if key_tie:
+            return "tie", 0.0, 0.0
         p = O.scaled_softmax_f16(target[node][None], T)[0]
         row = draft[node].copy()
         d = ulps2(target[node]) + ulps2(draft[node])
@@ -302,9 +328,16 @@ def _replay_record_on_gpu(path, prove=False):
                     if prove:
                         snap = dict(gt=spectree.ground_truth_len, tokens=spectree.tokens.clone(),
                                     draft=spectree.draft_logits[:tree_size].clone())
+                        real_filter = spectree.ops.top_p_filter
+
+                        def spy_filter(logits, top_p, temperature, snap=snap, real_filter=real_filter):
+                            snap["target_raw"] = logits[-tree_size:].clone().cpu().numpy()      # before the in-place cut
+                            return real_filter(logits, top_p, temperature)
+                        spectree.ops.top_p_filter = spy_filter
                     valid_tokens, draft_kv_len, target_kv_len, terminate = spectree.verify()
                     log.append((step, valid_tokens.cpu().numpy().copy()))
                     if prove:
+                        del spectree.ops.top_p_filter                  # (the instance attribute shadowing the method)
                         jj = len(log) - 1
                         if jj >= meta["n_verify"] or int(z["verify_prompt"][jj]) != step:
                             return z, meta, None, log, ("unexplained", "another number of verify calls")
