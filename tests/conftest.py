@@ -72,7 +72,9 @@ TOPP_TRACES = ["B_topp09"]
 WIDTH_TRACES = ["D_13b_w4", "E_70b_w2"]
 # configuration D at FULL DEPTH: Sheared-LLaMA-1.3B dims (24 layers) -> Llama-2-13b dims (40 layers), 26 GB of seeded weights
 # (two to three minutes of CPU generation on the GPU box, shared by the tests of one process)
-DEPTH_TRACES = ["D_13b"]
+DEPTH_TRACES = ["D_13b", "E_70b_w8"]
+# E_70b_w8 (round 6): configuration E at 70B WIDTHS and 8 LAYERS each side (17 GB of seeded fp16 weights): E_70b_w2 pins the
+# widths, this one the accumulation of rounding over depth at those widths
 # Round 5: the reference's LARGE growmaps -- 193 nodes / depth 24 (L40_growmaps/8x24-tree.pt, SpecTree and GreedyTree), 256 and
 # 512 nodes (A100-CNN-68m-13b-stochastic-S256 / -S512: 4 / 8 ancestor-bitmask words, up to 116 parents x 32 children per
 # level, verify forwards of 193-512 rows).  "lean" traces: the samplers' inputs are draft_logits_pre[roots[i]], rand[roots[i]]

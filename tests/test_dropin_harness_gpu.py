@@ -183,22 +183,37 @@ def _explain_divergence(z, meta, j, spectree, snap, prev_len, got):
     # walk the tree along the reference's accepted tokens, replaying the accept tests on this GPU's logits
     node, depth = 0, 0
     key_tie = False          # the path passed a parent where the accepted token's sampling key ties EXACTLY with a sibling's
+    fragile = None           # ... or lies within the two-ulp band of a sibling's: (log distance, limit) -- the siblings may be
+    #                          drafted in the other order, i.e. sit on swapped nodes with subtrees of other shapes
     while True:
         kids = succ[node]
         want_tok = ref_acc[depth] if depth < len(ref_acc) else None
         want = next((c for c in kids if int(tokens_pre[gt - 1 + c]) == want_tok), None) if want_tok is not None else None
         have = got_nodes[depth] if depth < len(got_nodes) else None
+        if want_tok is not None and want is None and want_tok == int(ref[-1]) and have is not None:
+            # the reference's commit order stores the bonus token BEFORE it gathers the accepted tokens (Tree/SpecTree.py:222-224):
+            # an accepted node that sat at slot a shows the BONUS id in the reference's text -- the token itself is not
+            # recorded; follow this GPU's own node at that depth (the walks part further down, or at the bonus draw)
+            want = have
         if want is not None and len(kids) > 1:
             rand_ = spectree.rand[node].cpu().numpy()[None]
             keys_ = O.sample_keys(draft[node][None], rand_, T)[0]
             kt = [keys_[int(tokens_pre[gt - 1 + c])] for c in kids]
-            key_tie = key_tie or sum(1 for k_ in kt if k_ == keys_[want_tok]) > 1
+            kw_ = float(keys_[int(tokens_pre[gt - 1 + want])])
+            key_tie = key_tie or sum(1 for k_ in kt if k_ == keys_[int(tokens_pre[gt - 1 + want])]) > 1
+            if np.isfinite(kw_) and kw_ < 0:
+                near = [abs(np.log(-kw_) - np.log(-float(k_))) for c_, k_ in zip(kids, kt) if c_ != want and np.isfinite(k_) and k_ < 0]
+                lim_ = 4 * ulps2(draft[node])
+                if near and min(near) <= lim_ and fragile is None:
+                    fragile = (float(min(near)), lim_)
         if want_tok is not None and want is None:
             if key_tie or not kids:
                 # an exact tie of fp16 sampling keys further up the accepted path: torch.topk leaves the order inside the tie
                 # unspecified (here: lowest token id first), the tied tokens sit on swapped sibling nodes, and the growmap
                 # gives those nodes subtrees of other shapes -- the reference's next accepted token has no node here
                 return ("tie", 0.0, 0.0) if key_tie else ("unexplained", "the reference accepted below a leaf of this tree", 0)
+            if fragile is not None:
+                return "sampler", fragile[0], fragile[1]
             rand = spectree.rand[node].cpu().numpy()[None]
             keys = O.sample_keys(draft[node][None], rand, T)[0].astype(np.float64)
             kmin = min(float(keys[int(tokens_pre[gt - 1 + c])]) for c in kids)
@@ -233,6 +248,19 @@ def _explain_divergence(z, meta, j, spectree, snap, prev_len, got):
                     return "tie", 0.0, 0.0
         if key_tie:
             return "tie", 0.0, 0.0
+        if fragile is not None:
+            return "sampler", fragile[0], fragile[1]
+        if want is not None and have is not None:
+            # both tokens were drafted for this parent: were they drafted in the other ORDER?  The accept tests run in child
+            # order (Tree/SpecTree.py:136-157) and the first accepted child wins, so two sampling keys within the two-ulp
+            # band may swap the siblings and with them the outcome
+            rand_ = spectree.rand[node].cpu().numpy()[None]
+            keys_ = O.sample_keys(draft[node][None], rand_, T)[0].astype(np.float64)
+            kw, kh = float(keys_[int(tokens_pre[gt - 1 + want])]), float(keys_[int(tokens_pre[gt - 1 + have])])
+            if np.isfinite(kw) and np.isfinite(kh) and kw < 0 and kh < 0:
+                xk = abs(np.log(-kw) - np.log(-kh))
+                if xk <= 4 * ulps2(draft[node]):
+                    return "sampler", float(xk), 4 * ulps2(draft[node])
         p = O.scaled_softmax_f16(target[node][None], T)[0]
         row = draft[node].copy()
         d = ulps2(target[node]) + ulps2(draft[node])
@@ -379,7 +407,10 @@ def test_unscreened_reference_harness_seeds_on_gpu(tree):
       * an accept test p > r q, or a draft token at the top-k cut of its parent's sampling keys, that two fp16 ulps on the
         logits involved (|logit| reaches 60 here: an ulp is 0.03-0.06, i.e. 5-10 % of a probability at T = 0.6) flip.
       * an exact tie among sampling keys of -inf (fewer non-zero-probability tokens than children to draw).
-    Runs that part any other way are listed as unexplained and bounded (a quarter of the runs at most).  The counts are printed
+      * an order torch leaves unspecified: exact ties of sampling keys (torch.topk) and the nucleus cut inside a class of
+        equal logits (the unstable CPU sort) -- or two sibling keys inside the two-ulp band: the siblings are then drafted in
+        the other order, the accept tests run in child order, and the swapped nodes carry subtrees of other shapes.
+    Runs that part any other way are listed as unexplained and bounded (2 of 20; 0 of 40 on the round's boxes).  The counts are printed
     in the session summary (tests/conftest.py)."""
     import glob
     import helpers
@@ -404,4 +435,4 @@ def test_unscreened_reference_harness_seeds_on_gpu(tree):
     # from the reference's at a decision two ulps per logit do NOT explain stay rare (they are listed, not hidden: exact ties
     # inside the nucleus cut and other orders the reference leaves to torch's unstable CPU sort end up here)
     assert identical >= len(paths) // 2, (identical, explained, unexplained)
-    assert len(unexplained) <= len(paths) // 4, unexplained
+    assert len(unexplained) <= 2, unexplained

@@ -12,7 +12,7 @@ import pytest
 from conftest import (COMPACT_TRACES, GOLDEN, LARGE_COMPACT, LARGE_GREEDY, LARGE_STOCHASTIC, LARGE_TRACES, STOCHASTIC_TRACES,
                       TOPP_TRACES, TRACE_NAMES, load_trace)
 
-COMPACT_STOCHASTIC = COMPACT_TRACES + TOPP_TRACES + ["B_7b", "D_13b_w4", "E_70b_w2", "D_13b"] + LARGE_COMPACT        # + the headline-dims SpecTree trace (68m -> 7B dims)
+COMPACT_STOCHASTIC = COMPACT_TRACES + TOPP_TRACES + ["B_7b", "D_13b_w4", "E_70b_w2", "D_13b", "E_70b_w8"] + LARGE_COMPACT        # + the headline-dims SpecTree trace (68m -> 7B dims)
 from oracle import ops_np as O
 
 

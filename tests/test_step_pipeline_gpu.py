@@ -24,7 +24,7 @@ def _sync_run(z, meta, n_steps):
 
 
 @pytest.mark.parametrize("name", ["demo4", "B_seq128", "D_160m13b", "C_greedy8x8", "V32k_seq128", "B_topp09", "B_7b", "C_7b", "D_13b_w4",
-                                  "E_70b_w2", "D_13b", "L_8x24", "L_8x24_greedy", "L_S256", "L_S512", "L_S256_v32k"])
+                                  "E_70b_w2", "D_13b", "E_70b_w8", "L_8x24", "L_8x24_greedy", "L_S256", "L_S512", "L_S256_v32k"])
 def test_step_graph_equals_synchronous_steps(name):
     """(L_*: the reference's 193- / 256- / 512-node growmaps.  Their verify forward has more than 144 rows, so inside the
     captured step it runs on the general path -- sq_stage_tree_inputs as a launch of its own, hipBLASLt projections captured
