@@ -53,9 +53,14 @@ struct TsParams {
 
 
 // row tiles per merge pass: 4 wave images of [16 MH][16 NT + 4] fp32 must fit 150 KB of LDS
+// (experiment switches, tools/ts_dbg_build.sh: TS_MERGE_KB caps the merge area -- 70 lets TWO workgroups share a compute unit --,
+// TS_FORCE_D fixes the ring depth)
+#ifndef TS_MERGE_KB
+#define TS_MERGE_KB 150
+#endif
 constexpr int ts_merge_tiles(int mt, int nt) {
     const int per_tile = TS_WAVES * 16 * (nt * 16 + 4) * 4;
-    const int fit = (150 * 1024) / per_tile;
+    const int fit = (TS_MERGE_KB * 1024) / per_tile;
     return fit >= mt ? mt : fit;
 }
 
@@ -287,7 +292,11 @@ static void ts_go(const TsParams& P, hipStream_t st) {
     // wave-private LDS ring, hand-counted waits: 27.6 vs 29.6 us on the 128-row qkv, 64 vs 62 us on gate_up) are no
     // faster -- the stream is bound by the CU's memory ingest (~14 B/clk/CU for weights + activations together),
     // not by bytes in flight or by the VGPR return path.
+#ifdef TS_FORCE_D
+    constexpr int D = TS_FORCE_D;
+#else
     constexpr int D = (MT * NT > 48) ? 2 : ((MT * NT > 24) ? 3 : 4);     // 8 x 8 accumulator tiles: 256 registers, ring of 2
+#endif
     const size_t lds = (size_t)TS_WAVES * ts_merge_tiles(MT, NT) * 16 * (NT * 16 + 4) * sizeof(float);
     void (*kern)(const TsParams);
     if constexpr (TAIL) kern = ts_linear_tail_kernel<MT, NT, D, SILU>;
