@@ -32,7 +32,10 @@
 #include <stdlib.h>
 
 // Compile-time experiment switches (-DTS_DBG=bits, tools/ts_dbg_build.sh): 1 = activations from one k-step (L1 hits),
-// 2 = weights likewise, 4 = no MFMA, 8 = no loads in the loop, 16 = no prologue loads, 32 = no merge / stores.
+// 2 = weights likewise, 4 = no MFMA (INVALID as a timing: with the MFMAs gone the compiler deletes a third of the loop's loads
+// and every s_waitcnt -- round 6 found the loop of that build without a single wait), 64 = no MFMA but every operand
+// fragment still consumed by an empty asm statement (loads and waits stay: the valid "loads only" build),
+// 8 = no loads in the loop, 16 = no prologue loads, 32 = no merge / stores.
 // They must not be run-time branches: a conditional around the loads makes the
 // compiler drain vmcnt at the join and the kernel loses a third of its speed (measured).
 #ifndef TS_DBG
@@ -142,6 +145,10 @@ __device__ __forceinline__ void ts_linear_body(const TsParams& P) {
     }
 #define TS_MMA(d)                                                                                      \
     {                                                                                                  \
+        if (TS_DBG & 64) {                                                                             \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) asm volatile("" :: "v"(ar[d][mt]));      \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) asm volatile("" :: "v"(wr[d][t]));          \
+        } else                                                                                         \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
             _Pragma("unroll") for (int t = 0; t < NT; ++t)                                             \
                 acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[d][mt], wr[d][t], acc[mt][t], 0, 0, 0); \
