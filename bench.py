@@ -332,7 +332,7 @@ def main():
                     other["A"]["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}")
             cpu_keep.clear()
             import gc
-            for oc, osteps in (("D", args.other_steps), ("E", min(args.other_steps, 12))):
+            for oc, osteps in (("D", args.other_steps), ("L", args.other_steps), ("E", min(args.other_steps, 12))):
                 if oc == "E" and args.no_config_e:
                     continue
                 try:

@@ -87,7 +87,7 @@ def run_other_config(name, args, device, prompts, engines=None, steps=20, warmup
     torch.cuda.synchronize()
     pf_n, pf_s, pf_t = loop.prefill_steps - p0, loop.prefill_seconds - ps0, loop.prefill_tokens - pt0
     kr = kernel_rooflines(cfg, loop, device)
-    per_step = {k: v["seconds"] * v["launches_per_step"] if (k == "tree_attention_target" or k.startswith("linear_ts_")) else v["seconds"]
+    per_step = {k: v["seconds"] * v["launches_per_step"] if (k == "tree_attention_target" or k.startswith(("linear_ts_", "gemm_"))) else v["seconds"]
                 for k, v in kr.items()}
     dom = max(per_step, key=per_step.get)
     d = kr[dom]

@@ -212,6 +212,24 @@ def kernel_rooflines(cfg, loop, device):
             out_bytes = splits * n * (w_rows if silu else n_out) * 4 if splits > 1 else n * n_out * 2
             res[f"linear_ts_{name}"] = dict(seconds=t, bytes=w_rows * k * 2 + n * k * 2 + out_bytes, launches_per_step=L,
                                             flops=2 * n * w_rows * k, plan=[tiles, splits], pmc_key=f"{name}@{(n + 15) // 16}")
+    elif n > TS_MAX_ROWS and all(getattr(tgt.model.weights.layers[0], a, None) is not None for a in ("wqkv", "wo", "w_gate_up", "w_down")):
+        # more than 144 rows (the reference's 193- / 256- / 512-node growmaps): the verify forward's projections are hipBLASLt
+        # GEMMs on the row-major weights -- timed the same way, rotating over the layers' weights
+        import torch.nn.functional as F
+        W = tgt.model.weights
+        for name, attr in (("qkv", "wqkv"), ("o", "wo"), ("gate_up", "w_gate_up"), ("down", "w_down")):
+            w0 = getattr(W.layers[0], attr)
+            n_rows, k = w0.shape
+            x = (torch.randn(n, k, device=device) * 0.5).half()
+            li = [0]
+
+            def gemm(attr=attr, x=x):
+                y = F.linear(x, getattr(W.layers[li[0] % L], attr))
+                li[0] += 1
+                return y
+            t = timeit(gemm, 64, 32)
+            res[f"gemm_{name}"] = dict(seconds=t, bytes=n_rows * k * 2 + n * k * 2 + n * n_rows * 2, launches_per_step=L,
+                                       flops=2 * n * n_rows * k, plan="hipBLASLt")
     return res
 
 

@@ -24,6 +24,8 @@ GROWMAPS = {
     "64x2-tree": "L40_growmaps/64x2-tree.pt",
     "demo_tree": "demo_tree.pt",
     "16x8-tree": "L40_growmaps/16x8-tree.pt",
+    # round 6: the large-tree path gets a bench line (other_configs.L: 68m -> Llama-2-13b dims, 256 nodes, M = 512)
+    "A100-CNN-68m-13b-stochastic-S256": "A100_growmaps/68m_13b/growmaps/A100-CNN-68m-13b-stochastic-S256.pt",
 }
 
 

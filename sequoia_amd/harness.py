@@ -27,6 +27,10 @@ MODELS = {
     "C": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-7b-hf", growmap="8x8-tree", mode="greedy", M=384),
     "D": dict(draft="princeton-nlp/Sheared-LLaMA-1.3B", target="meta-llama/Llama-2-13b-hf",
               growmap="A100-CNN-160m-13b-stochastic", mode="stochastic", M=384),
+    # the large-tree path (README.md:47,54: the reference's 256-node growmap, M >= tree + 256): a verify forward of 256 rows,
+    # beyond the tall-skinny kernel's 144 -- hipBLASLt projections inside the captured step
+    "L": dict(draft="JackFram/llama-68m", target="meta-llama/Llama-2-13b-hf", growmap="A100-CNN-68m-13b-stochastic-S256",
+              mode="stochastic", M=512),
     # 70B target sharded tensor-parallel over all launched ranks (replaces the reference's host offload);
     # every rank runs the replicated draft + verifier, so N ranks serve ONE request stream ("strong")
     "E": dict(draft="meta-llama/Llama-2-7b-hf", target="meta-llama/Llama-2-70b-hf", growmap="64x2-tree",
