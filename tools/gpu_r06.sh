@@ -1,5 +1,10 @@
 # GPU-box stages of round 6 (run through gpurun; everything lands under gpurun_out/r06/):
 #   bash tools/gpu_r06.sh <stage> [<stage> ...]
+#   block     the fused draft kernels (csrc/draft_block.hip) against the launches they replace + the oracle
+#   traces    every end-to-end replay of the reference's traces
+#   components  the 128-row projections on the TS_DBG experiment builds (tools/ts_dbg_build.sh first); tools/ts_components_loads_only.sh,
+#             tools/ts_occ2.sh: the loads-only builds and the two-workgroups-per-CU build
+#   tp8       configuration E at TP = 8, eight ranks on the one GPU (functional)
 #   large     the round's new parity surface: the reference's 193- / 256- / 512-node growmaps (kernel level, host-driven loop, whole-step graphs)
 #   kernels   tests/test_hip_kernels.py (every C-ABI kernel against the oracle)
 #   tests     the whole GPU suite + smoke()
